@@ -1,0 +1,486 @@
+// hrt_runtime.hip -- libhip_raytrace.so: kernels' entry points + the C ABI of
+// include/hip_raytrace.h (context, scene upload, frame render, multi-device row tiling).
+//
+// Replaces the ILGPU accelerator / kernel-launch layer of the reference
+// (Engine/RTRenderer.cs:66-68,85-86,118-120,152-153,164,181-205,233; Engine/Scene.cs:258-279,
+//  370-377; Engine/Framebuffer.cs:60-97,127-146,228-253).  HIP runtime only: no torch, no
+// CPU fallback -- every entry point fails with HRT_ERR_NO_DEVICE / HRT_ERR_HIP when no
+// MI355X is usable.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hrt_device.hpp"
+#include "../../include/hip_raytrace.h"
+
+using namespace hrt;
+
+// ---------------------------------------------------------------------------------------
+// Pixel <-> lane mapping.  A 256-thread workgroup shades a 32x8 pixel tile: each of its 4
+// waves owns one 8x8 sub-tile (lane l -> (l&7, l>>3)), so the 64 rays of a wave leave the
+// camera through a compact square and walk nearly the same BVH nodes.  Workgroup ids are
+// dealt round-robin over the 8 XCDs by the dispatcher; remap() hands every XCD one
+// contiguous band of tiles so each private 4 MiB L2 caches one region of the BVH instead
+// of all of it (bijective form of the T1 remap, cdna_hip_programming.md).
+// ---------------------------------------------------------------------------------------
+struct TileMap { int tilesX, tilesY, nTiles; };
+
+__device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, int& x, int& y)
+{
+    int orig = blockIdx.x;
+    int q = tm.nTiles >> 3, r = tm.nTiles & 7;
+    int xcd = orig & 7, seq = orig >> 3;
+    int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+    int ty = tile / tm.tilesX, tx = tile - ty * tm.tilesX;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    x = tx * 32 + wave * 8 + (lane & 7);
+    y = k.row_begin + ty * 8 + (lane >> 3);
+    return x < k.width && y < k.row_end;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_primary_kernel(DScene S, FrameK k, DGBuffer gb, TileMap tm, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int x, y;
+    if (tile_pixel(tm, k, x, y)) primary_pixel<COUNT>(S, k, gb, y * k.width + x, C);
+    C.flush(counters);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_path_trace_kernel(DScene S, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
+                      long long nPix, TileMap tm, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int x, y;
+    if (tile_pixel(tm, k, x, y)) path_trace_pixel<COUNT>(S, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
+    C.flush(counters);
+}
+
+// exactness probe: evaluates include/hrt_math.h on the device (tests compare with the oracle's bits)
+__global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float* y, float* out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y ? y[i] : 0.f, r = 0.f;
+    switch (fn) {
+    case 0: r = hrt_sin(a); break;   case 1: r = hrt_cos(a); break;   case 2: r = hrt_tan(a); break;
+    case 3: r = hrt_atan(a); break;  case 4: r = hrt_atan2(a, b); break; case 5: r = hrt_acos(a); break;
+    case 6: r = hrt_asin(a); break;  case 7: r = hrt_rsqrt(a); break; case 8: r = hrt_sqrt(a); break;
+    case 9: r = hrt_fmin(a, b); break; case 10: r = hrt_fmax(a, b); break;
+    case 11: r = hrt_floor(a); break; case 12: r = hrt_round(a); break;
+    case 13: { int v = hrt_f2i(a); r = __int_as_float(v); } break;
+    case 14: r = 1.0f / a; break;    case 15: r = a / b; break;
+    case 16: r = a * b + a; break;   // must NOT be contracted
+    }
+    out[i] = r;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DeviceState {
+    int device_id = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // scene (15 arrays)
+    void* scene[15] = {};
+    DScene dscene{};
+    // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
+    int64_t nPix = 0;
+    DGBuffer gb{};
+    DFramebuffer fb{};
+    DReservoir resA{}, resB{};
+    unsigned long long* counters = nullptr;   // 2 x 10
+    int row_begin = 0, row_end = 0;
+};
+
+} // namespace
+
+struct hrt_ctx {
+    std::vector<DeviceState> dev;
+    std::string err;
+    bool scene_ready = false;
+    int width = 0, height = 0;
+};
+
+namespace {
+
+const size_t kSceneElem[15] = {sizeof(hrt_bvh_node), 4, sizeof(hrt_instance), sizeof(hrt_bvh_node), 4, sizeof(hrt_sphere), 4,
+                               sizeof(hrt_float3), sizeof(hrt_mesh_tri), sizeof(hrt_float2), sizeof(hrt_mesh_tri_uv), 4,
+                               sizeof(hrt_material), sizeof(hrt_rgba32), sizeof(hrt_tex_info)};
+
+int fail(hrt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? HRT_ERR_OUT_OF_MEMORY : HRT_ERR_HIP,     \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                       \
+    } while (0)
+
+void free_pixels(DeviceState& d)
+{
+    void* ptrs[] = {d.gb.worldPos, d.gb.normalWS, d.gb.baseColor, d.gb.matId, d.gb.objId, d.gb.hitMask,
+                    d.fb.color, d.fb.depth, d.fb.objectId, d.fb.cameraId, d.fb.radiance,
+                    d.resA.L, d.resA.wi, d.resA.pdf, d.resA.w, d.resA.wSum, d.resA.m, d.resA.lightId,
+                    d.resB.L, d.resB.wi, d.resB.pdf, d.resB.w, d.resB.wSum, d.resB.m, d.resB.lightId};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d.gb = DGBuffer{}; d.fb = DFramebuffer{}; d.resA = DReservoir{}; d.resB = DReservoir{};
+    d.nPix = 0;
+}
+
+template <class T> hipError_t dalloc(T*& p, int64_t n, bool zero)
+{
+    void* v = nullptr;
+    hipError_t e = hipMalloc(&v, (size_t)n * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (zero) { e = hipMemset(v, 0, (size_t)n * sizeof(T)); if (e != hipSuccess) return e; }
+    p = static_cast<T*>(v);
+    return hipSuccess;
+}
+
+hipError_t alloc_res(DReservoir& r, int64_t n)
+{
+    hipError_t e;
+    if ((e = dalloc(r.L, n, true)) != hipSuccess) return e;
+    if ((e = dalloc(r.wi, n, true)) != hipSuccess) return e;
+    if ((e = dalloc(r.pdf, n, true)) != hipSuccess) return e;
+    if ((e = dalloc(r.w, n, true)) != hipSuccess) return e;
+    if ((e = dalloc(r.wSum, n, true)) != hipSuccess) return e;
+    if ((e = dalloc(r.m, n, true)) != hipSuccess) return e;
+    return dalloc(r.lightId, n, true);
+}
+
+// GBuffer.EnsureLength / Framebuffer.EnsureLength / EnsureLowResBuffers: realloc on size change only
+int ensure_pixels(hrt_ctx* c, DeviceState& d, int64_t nPix)
+{
+    if (d.nPix == nPix) return HRT_OK;
+    HIPCHK(c, hipSetDevice(d.device_id));
+    free_pixels(d);
+    HIPCHK(c, dalloc(d.gb.worldPos, nPix, true));
+    HIPCHK(c, dalloc(d.gb.normalWS, nPix, true));
+    HIPCHK(c, dalloc(d.gb.baseColor, nPix, true));
+    HIPCHK(c, dalloc(d.gb.matId, nPix, true));
+    HIPCHK(c, dalloc(d.gb.objId, nPix, true));
+    HIPCHK(c, dalloc(d.gb.hitMask, nPix, true));
+    HIPCHK(c, dalloc(d.fb.color, nPix, true));
+    HIPCHK(c, dalloc(d.fb.depth, nPix, true));
+    HIPCHK(c, dalloc(d.fb.objectId, nPix, true));
+    HIPCHK(c, dalloc(d.fb.cameraId, 1, true));
+    HIPCHK(c, dalloc(d.fb.radiance, nPix, true));
+    HIPCHK(c, alloc_res(d.resA, nPix));
+    HIPCHK(c, alloc_res(d.resB, nPix));
+    d.nPix = nPix;
+    return HRT_OK;
+}
+
+void free_scene(DeviceState& d)
+{
+    for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
+}
+
+template <class T>
+int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
+{
+    if (!host) return HRT_OK;
+    size_t off = (size_t)d.row_begin * width;
+    size_t cnt = (size_t)(d.row_end - d.row_begin) * width;
+    if (cnt == 0) return HRT_OK;
+    HIPCHK(c, hipMemcpyAsync(host + off, devp + off, cnt * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+    return HRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* hrt_version(void) { return "hip_raytrace 0.1 (gfx950)"; }
+
+int hrt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+const char* hrt_last_error(hrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
+{
+    if (!out) return fail(nullptr, HRT_ERR_INVALID_ARG, "hrt_create: out is NULL");
+    *out = nullptr;
+    int avail = 0;
+    hipError_t e = hipGetDeviceCount(&avail);
+    if (e != hipSuccess || avail <= 0)
+        return fail(nullptr, HRT_ERR_NO_DEVICE, std::string("hrt_create: no HIP device (") + hipGetErrorString(e) + ")");
+    std::vector<int> ids;
+    if (device_ids && n_dev > 0) ids.assign(device_ids, device_ids + n_dev);
+    else ids.push_back(0);
+    for (int id : ids)
+        if (id < 0 || id >= avail) return fail(nullptr, HRT_ERR_INVALID_ARG, "hrt_create: device id out of range");
+    hrt_ctx* c = new hrt_ctx();
+    c->dev.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); i++)
+    {
+        DeviceState& d = c->dev[i];
+        d.device_id = ids[i];
+        hipError_t err = hipSetDevice(d.device_id);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[k]);
+        if (err == hipSuccess) { void* p = nullptr; err = hipMalloc(&p, 20 * sizeof(unsigned long long)); d.counters = (unsigned long long*)p; }
+        if (err != hipSuccess)
+        {
+            std::string m = std::string("hrt_create: ") + hipGetErrorString(err);
+            hrt_destroy(c);
+            return fail(nullptr, HRT_ERR_HIP, m);
+        }
+    }
+    *out = c;
+    return HRT_OK;
+}
+
+void hrt_destroy(hrt_ctx* c)
+{
+    if (!c) return;
+    for (DeviceState& d : c->dev)
+    {
+        if (d.device_id < 0) continue;
+        (void)hipSetDevice(d.device_id);
+        if (d.stream) (void)hipStreamSynchronize(d.stream);
+        free_pixels(d);
+        free_scene(d);
+        if (d.counters) (void)hipFree(d.counters);
+        for (int k = 0; k < 4; k++) if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    delete c;
+}
+
+int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!s) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: scene is NULL");
+    const void* src[15] = {s->tlasNodes, s->tlasInstanceIndices, s->instances, s->blasNodes, s->spherePrimIdx, s->spheres,
+                           s->triPrimIdx, s->meshPositions, s->meshTris, s->meshTexcoords, s->meshTriUVs, s->triMatIndex,
+                           s->materials, s->texels, s->texInfos};
+    const int64_t cnt[15] = {s->n_tlasNodes, s->n_tlasInstanceIndices, s->n_instances, s->n_blasNodes, s->n_spherePrimIdx, s->n_spheres,
+                             s->n_triPrimIdx, s->n_meshPositions, s->n_meshTris, s->n_meshTexcoords, s->n_meshTriUVs, s->n_triMatIndex,
+                             s->n_materials, s->n_texels, s->n_texInfos};
+    for (int i = 0; i < 15; i++)
+        if (cnt[i] < 0 || (cnt[i] > 0 && !src[i])) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: array " + std::to_string(i) + " has a count but no pointer");
+    c->scene_ready = false;
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        HIPCHK(c, hipStreamSynchronize(d.stream));
+        free_scene(d);                                  // UploadAll disposes + reallocates all 15 (Scene.cs:260-278)
+        for (int i = 0; i < 15; i++)
+        {
+            int64_t n = cnt[i] > 0 ? cnt[i] : 1;       // AllocateOrEmpty: empty -> 1 zeroed element
+            size_t bytes = (size_t)n * kSceneElem[i];
+            HIPCHK(c, hipMalloc(&d.scene[i], bytes));
+            if (cnt[i] > 0) HIPCHK(c, hipMemcpy(d.scene[i], src[i], bytes, hipMemcpyHostToDevice));
+            else HIPCHK(c, hipMemset(d.scene[i], 0, bytes));
+        }
+        DScene& S = d.dscene;
+        S.tlasNodes = (const hrt_bvh_node*)d.scene[0]; S.tlasInst = (const int32_t*)d.scene[1];
+        S.instances = (const hrt_instance*)d.scene[2]; S.blasNodes = (const hrt_bvh_node*)d.scene[3];
+        S.spherePrimIdx = (const int32_t*)d.scene[4]; S.spheres = (const hrt_sphere*)d.scene[5];
+        S.triPrimIdx = (const int32_t*)d.scene[6]; S.meshPositions = (const hrt_float3*)d.scene[7];
+        S.meshTris = (const hrt_mesh_tri*)d.scene[8]; S.meshTexcoords = (const hrt_float2*)d.scene[9];
+        S.meshTriUVs = (const hrt_mesh_tri_uv*)d.scene[10]; S.triMatIndex = (const int32_t*)d.scene[11];
+        S.materials = (const hrt_material*)d.scene[12]; S.texels = (const hrt_rgba32*)d.scene[13];
+        S.texInfos = (const hrt_tex_info*)d.scene[14];
+        S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
+    }
+    c->scene_ready = true;
+    return HRT_OK;
+}
+
+int hrt_reset_history(hrt_ctx* c)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    for (DeviceState& d : c->dev)
+    {
+        if (d.nPix == 0) continue;
+        HIPCHK(c, hipSetDevice(d.device_id));
+        DReservoir* rs[2] = {&d.resA, &d.resB};
+        for (DReservoir* r : rs)
+        {
+            HIPCHK(c, hipMemsetAsync(r->L, 0, d.nPix * 12, d.stream)); HIPCHK(c, hipMemsetAsync(r->wi, 0, d.nPix * 12, d.stream));
+            HIPCHK(c, hipMemsetAsync(r->pdf, 0, d.nPix * 4, d.stream)); HIPCHK(c, hipMemsetAsync(r->w, 0, d.nPix * 4, d.stream));
+            HIPCHK(c, hipMemsetAsync(r->wSum, 0, d.nPix * 4, d.stream)); HIPCHK(c, hipMemsetAsync(r->m, 0, d.nPix * 4, d.stream));
+            HIPCHK(c, hipMemsetAsync(r->lightId, 0, d.nPix * 4, d.stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(d.stream));
+    }
+    return HRT_OK;
+}
+
+int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opts* opts, const hrt_outputs* out, hrt_stats* stats)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!p) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: params is NULL");
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: no scene uploaded (call hrt_scene_upload first)");
+    if (p->width <= 0 || p->height <= 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: width/height must be positive");
+    if ((int64_t)p->width * p->height > 0x7FFFFFFFLL) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: image too large for int pixel indices");
+    if (p->maxDepth < 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: maxDepth must be >= 0");
+    uint32_t flags = opts ? opts->flags : 0u;
+    int rb = opts ? opts->row_begin : 0, re = opts ? opts->row_end : 0;
+    if (rb == 0 && re == 0) re = p->height;
+    if (rb < 0 || re > p->height || rb > re) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: row range outside the image");
+    const bool reuse = (p->enableTemporalReuse != 0 || p->enableSpatialReuse != 0);
+    const int nd = (int)c->dev.size();
+    if (reuse && (nd > 1 || rb != 0 || re != p->height))
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse across row tiles needs the G-buffer/reservoir exchange step (not built yet); render reuse frames on one full-image tile");
+    const int64_t nPix = (int64_t)p->width * p->height;
+    const bool count = (flags & HRT_FLAG_COUNTERS) != 0;
+
+    // contiguous row blocks, 8-row granularity so wave tiles never straddle two devices
+    int rows = re - rb;
+    int units = (rows + 7) / 8;
+    for (int i = 0; i < nd; i++)
+    {
+        int u0 = (int)((int64_t)units * i / nd), u1 = (int)((int64_t)units * (i + 1) / nd);
+        c->dev[i].row_begin = std::min(re, rb + u0 * 8);
+        c->dev[i].row_end = std::min(re, rb + u1 * 8);
+    }
+
+    for (DeviceState& d : c->dev)
+    {
+        int rc = ensure_pixels(c, d, nPix);
+        if (rc != HRT_OK) return rc;
+    }
+    c->width = p->width; c->height = p->height;
+
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        FrameK k;
+        k.width = p->width; k.height = p->height; k.frame = p->frame;
+        k.row_begin = d.row_begin; k.row_end = d.row_end;
+        k.cam = p->cam; k.prevCam = p->prevCam;
+        k.dirLightDir = p->dirLightDir; k.dirLightRadiance = p->dirLightRadiance;
+        k.skyTop = p->skyTintTop; k.skyBottom = p->skyTintBottom;
+        k.debugCamSeq = p->debugCamSeq; k.enableTemporal = p->enableTemporalReuse; k.enableSpatial = p->enableSpatialReuse;
+        k.rngLockNoise = p->rngLockNoise; k.spp = p->spp; k.maxDepth = p->maxDepth;
+
+        TileMap tm;
+        tm.tilesX = (p->width + 31) / 32;
+        tm.tilesY = (d.row_end - d.row_begin + 7) / 8;
+        tm.nTiles = tm.tilesX * tm.tilesY;
+        if (count) HIPCHK(c, hipMemsetAsync(d.counters, 0, 20 * sizeof(unsigned long long), d.stream));
+        // Framebuffer.GetReservoirPair: even frame -> prev = B, cur = A (Framebuffer.cs:132-145)
+        const bool even = (p->frame & 1) == 0;
+        DReservoir resPrev = even ? d.resB : d.resA;
+        DReservoir resCur = even ? d.resA : d.resB;
+        DFramebuffer fb = d.fb;
+        if (d.device_id != c->dev[0].device_id || d.row_begin != 0) { /* cameraId[0] is written by pixel 0's owner only */ }
+
+        HIPCHK(c, hipEventRecord(d.ev[0], d.stream));
+        if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
+        {
+            if (count) hipLaunchKernelGGL(hrt_primary_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
+            else       hipLaunchKernelGGL(hrt_primary_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(d.ev[1], d.stream));
+        if (tm.nTiles > 0)
+        {
+            if (count) hipLaunchKernelGGL(hrt_path_trace_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
+            else       hipLaunchKernelGGL(hrt_path_trace_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
+            HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(d.ev[2], d.stream));
+
+        if (out)
+        {   // per-tile gather into the caller's host framebuffer
+            const int W = p->width;
+            int rc;
+#define G(hostp, devp) if ((rc = gather_rows(c, d, hostp, devp, W)) != HRT_OK) return rc
+            G(out->color, d.fb.color); G(out->depth, d.fb.depth); G(out->objectId, d.fb.objectId);
+            G(out->radiance, d.fb.radiance);
+            G(out->gb_worldPos, d.gb.worldPos); G(out->gb_normalWS, d.gb.normalWS); G(out->gb_baseColor, d.gb.baseColor);
+            G(out->gb_matId, d.gb.matId); G(out->gb_objId, d.gb.objId); G(out->gb_hitMask, d.gb.hitMask);
+            G(out->res_L, resCur.L); G(out->res_wi, resCur.wi); G(out->res_pdf, resCur.pdf); G(out->res_w, resCur.w);
+            G(out->res_wSum, resCur.wSum); G(out->res_m, resCur.m); G(out->res_lightId, resCur.lightId);
+#undef G
+            if (out->cameraId && d.row_begin == 0 && d.row_end > 0)
+                HIPCHK(c, hipMemcpyAsync(out->cameraId, d.fb.cameraId, 4, hipMemcpyDeviceToHost, d.stream));
+        }
+        HIPCHK(c, hipEventRecord(d.ev[3], d.stream));
+    }
+
+    hrt_stats st; std::memset(&st, 0, sizeof(st));
+    st.n_devices = nd; st.counters_valid = count ? 1 : 0;
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        HIPCHK(c, hipStreamSynchronize(d.stream));        // _cuda.Synchronize(), RTRenderer.cs:233
+        float ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[0], d.ev[1])); st.kernel_ms[0] = std::max(st.kernel_ms[0], (double)ms);
+        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[1], d.ev[2])); st.kernel_ms[1] = std::max(st.kernel_ms[1], (double)ms);
+        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[2], d.ev[3])); st.d2h_ms = std::max(st.d2h_ms, (double)ms);
+        if (count)
+        {
+            unsigned long long h[20];
+            HIPCHK(c, hipMemcpy(h, d.counters, sizeof(h), hipMemcpyDeviceToHost));
+            for (int kk = 0; kk < 2; kk++)
+            {
+                uint64_t* dst = reinterpret_cast<uint64_t*>(&st.k[kk]);
+                for (int i = 0; i < 10; i++) dst[i] += h[kk * 10 + i];
+            }
+        }
+    }
+    if (stats) *stats = st;
+    return HRT_OK;
+}
+
+int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
+{
+    if (!c || !o) return HRT_ERR_INVALID_ARG;
+    if (dev < 0 || dev >= (int)c->dev.size()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_device_buffers: device slot out of range");
+    DeviceState& d = c->dev[dev];
+    if (d.nPix == 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_device_buffers: no frame rendered yet");
+    size_t off = (size_t)d.row_begin * c->width;
+    o->row_begin = d.row_begin; o->row_end = d.row_end; o->width = c->width; o->device_id = d.device_id;
+    o->color = d.fb.color + off; o->depth = d.fb.depth + off; o->objectId = d.fb.objectId + off; o->radiance = d.fb.radiance + off;
+    o->gb_worldPos = d.gb.worldPos + off; o->gb_normalWS = d.gb.normalWS + off; o->gb_baseColor = d.gb.baseColor + off;
+    o->gb_matId = d.gb.matId + off; o->gb_objId = d.gb.objId + off; o->gb_hitMask = d.gb.hitMask + off;
+    return HRT_OK;
+}
+
+// test hook: evaluate hrt_math.h function `fn` on device 0 of ctx (see hrt_math_probe_kernel)
+int hrt_math_probe(hrt_ctx* c, int fn, int n, const float* x, const float* y, float* out)
+{
+    if (!c || !x || !out || n <= 0) return HRT_ERR_INVALID_ARG;
+    DeviceState& d = c->dev[0];
+    HIPCHK(c, hipSetDevice(d.device_id));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc((void**)&dx, (size_t)n * 4));
+    HIPCHK(c, hipMalloc((void**)&dout, (size_t)n * 4));
+    HIPCHK(c, hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    if (y) { HIPCHK(c, hipMalloc((void**)&dy, (size_t)n * 4)); HIPCHK(c, hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(hrt_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, d.stream, fn, n, dx, dy, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(d.stream));
+    HIPCHK(c, hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout); if (dy) (void)hipFree(dy);
+    return HRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,335 @@
+"""Host-side mirror of the reference's Engine API for the render path, over the C ABI.
+
+The reference's host is C# (`Engine/RTRenderer.cs`, `Engine/Scene.cs`, `Engine/SceneManager.cs`,
+`Engine/Camera.cs`); there is no .NET toolchain in this image, so this module plays the
+C# host's role from Python with the same class / method names and argument meaning:
+
+    Scene.AddSphere / BuildSphereInstance / LoadObjInstance* / RebuildTLAS / BuildDefaultScene
+    SceneManager.Commit  ->  RTRenderer.commit(scene)      (Scene.UploadAll, Scene.cs:258-279)
+    RTRenderer.RenderDirectToPbo(pbo, w, h, frame, dt) -> RTRenderer.render_frame(w, h, frame, dt, outputs)
+    RTRenderer.SetSunParams, Camera.CreateCamera / look-at ctor / Translate
+
+(* the array-append half; the OBJ file parser is out of scope.)
+
+Everything computed here is plumbing: the scene builders, camera math and the two kernels
+all live in libhip_raytrace.so (csrc/).  There is NO fallback: if the library or a GPU is
+missing, constructing RTRenderer raises.
+"""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+
+from . import _types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhip_raytrace.so")
+_LIB = None
+
+
+class HrtError(RuntimeError):
+    """A C-ABI call returned a negative hrt_status."""
+
+    def __init__(self, code, msg):
+        super().__init__("hip_raytrace error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads libhip_raytrace.so (built by `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhip_raytrace.so is not built (%s). Run __graft_entry__.build(); "
+                              "there is no CPU fallback for the render path." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.hrt_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+        L.hrt_destroy.argtypes = [C.c_void_p]
+        L.hrt_destroy.restype = None
+        L.hrt_last_error.argtypes = [C.c_void_p]
+        L.hrt_last_error.restype = C.c_char_p
+        L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+        L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
+        L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
+        L.hrt_reset_history.argtypes = [C.c_void_p]
+        L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hrt_device_count.restype = C.c_int
+        L.hrt_version.restype = C.c_char_p
+        L.hrth_scene_new.restype = C.c_void_p
+        L.hrth_scene_free.argtypes = [C.c_void_p]
+        L.hrth_scene_free.restype = None
+        L.hrth_scene_clear.argtypes = [C.c_void_p]
+        L.hrth_scene_build_default.argtypes = [C.c_void_p]
+        L.hrth_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.hrth_scene_add_sphere.argtypes = [C.c_void_p, C.POINTER(T.Sphere)]
+        L.hrth_scene_build_sphere_instance.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(T.Affine3x4)]
+        L.hrth_scene_load_mesh_instance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
+        L.hrth_scene_rebuild_tlas.argtypes = [C.c_void_p]
+        L.hrth_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+        L.hrth_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
+        L.hrth_camera_lookat.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
+        L.hrth_camera_translate.argtypes = [C.POINTER(T.Camera), C.POINTER(C.c_float)]
+        L.hrth_camera_bake.argtypes = [C.POINTER(T.Camera), C.c_int, C.c_int]
+        L.hrth_sun_dir.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+        _LIB = L
+    return _LIB
+
+
+def _fv(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+# ------------------------------------------------------------------ Camera (Engine/Camera.cs)
+def create_camera(width, height, fov_degrees):
+    """Camera.CreateCamera (Camera.cs:19-47)."""
+    c = T.Camera()
+    lib().hrth_camera_create(width, height, fov_degrees, C.byref(c))
+    return c
+
+
+def camera_look_at(origin, look_at, up, vfov_degrees, aspect, focus_dist=1.0):
+    """new Camera(origin, lookAt, up, vfovDegrees, aspect, focusDist) (Camera.cs:100-119)."""
+    c = T.Camera()
+    lib().hrth_camera_lookat(_fv(origin), _fv(look_at), _fv(up), vfov_degrees, aspect, focus_dist, C.byref(c))
+    return c
+
+
+def camera_translate(cam, delta):
+    """Camera.Translate (Camera.cs:121-126)."""
+    lib().hrth_camera_translate(C.byref(cam), _fv(delta))
+
+
+def bake_camera_derived(cam, pixel_w, pixel_h):
+    """RTRenderer.BakeCameraDerived (RTRenderer.cs:241-263)."""
+    lib().hrth_camera_bake(C.byref(cam), pixel_w, pixel_h)
+
+
+def sun_direction(azimuth, elevation):
+    o = (C.c_float * 3)()
+    lib().hrth_sun_dir(azimuth, elevation, o)
+    return [float(v) for v in o]
+
+
+def copy_camera(cam):
+    c = T.Camera()
+    C.memmove(C.byref(c), C.byref(cam), C.sizeof(T.Camera))
+    return c
+
+
+# ------------------------------------------------------------------ mesh container (MeshHost, MeshLoaderOBJ.cs:21-31)
+class MeshData:
+    """Arrays of one mesh as MeshLoaderOBJ.Load would return them (MeshHost)."""
+
+    def __init__(self, positions, triangles, texcoords, tri_uvs, materials, tri_material_index=None, textures_bgra=()):
+        self.positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        self.triangles = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        self.texcoords = np.ascontiguousarray(texcoords, dtype=np.float32).reshape(-1, 2)
+        self.tri_uvs = np.ascontiguousarray(tri_uvs, dtype=np.int32).reshape(-1, 3)
+        self.materials = (T.MaterialRecord * len(materials))(*materials)
+        self.n_materials = len(materials)
+        self.tri_mat = None if tri_material_index is None else np.ascontiguousarray(tri_material_index, dtype=np.int32)
+        self.tex_w = np.array([t.shape[1] for t in textures_bgra], dtype=np.int32)
+        self.tex_h = np.array([t.shape[0] for t in textures_bgra], dtype=np.int32)
+        self.tex_bytes = np.concatenate([np.ascontiguousarray(t, dtype=np.uint8).reshape(-1) for t in textures_bgra]) \
+            if len(textures_bgra) else np.zeros(0, np.uint8)
+        self.n_tex = len(textures_bgra)
+        assert len(self.tri_uvs) == len(self.triangles)
+
+    def ptrs(self):
+        return (self.positions.ctypes.data, len(self.positions), self.triangles.ctypes.data, len(self.triangles),
+                self.texcoords.ctypes.data, len(self.texcoords), self.tri_uvs.ctypes.data,
+                self.tri_mat.ctypes.data if self.tri_mat is not None else None, len(self.tri_mat) if self.tri_mat is not None else 0,
+                C.cast(self.materials, C.c_void_p), self.n_materials,
+                self.tex_w.ctypes.data if self.n_tex else None, self.tex_h.ctypes.data if self.n_tex else None,
+                self.tex_bytes.ctypes.data if self.n_tex else None, self.n_tex)
+
+
+# ------------------------------------------------------------------ Scene (Engine/Scene.cs, host lists + builders)
+class Scene:
+    def __init__(self):
+        self._h = lib().hrth_scene_new()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().hrth_scene_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def build_default_scene(self):
+        """Scene.BuildDefaultScene (Scene.cs:83-142)."""
+        lib().hrth_scene_build_default(self._h)
+
+    def add_texture(self, rgba):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        h, w = rgba.shape[:2]
+        r = lib().hrth_scene_add_texture(self._h, w, h, rgba.ctypes.data)
+        if r < 0:
+            raise ValueError("add_texture: invalid texture")
+        return r
+
+    def add_sphere(self, sphere):
+        """Scene.AddSphere (Scene.cs:315-321)."""
+        return lib().hrth_scene_add_sphere(self._h, C.byref(sphere))
+
+    def build_sphere_instance(self, sphere_ids, object_to_world=None):
+        """Scene.BuildSphereInstance (Scene.cs:323-356); the record is appended to the instance list."""
+        ids = list(sphere_ids)
+        arr = (C.c_int * len(ids))(*ids)
+        m = object_to_world if object_to_world is not None else T.identity_affine()
+        r = lib().hrth_scene_build_sphere_instance(self._h, arr, len(ids), C.byref(m))
+        if r < 0:
+            raise ValueError("build_sphere_instance: invalid sphere ids")
+        return r
+
+    def load_mesh_instance(self, mesh, object_to_world=None):
+        """Scene.LoadObjInstance after MeshLoaderOBJ.Load (Scene.cs:151-256)."""
+        m = object_to_world if object_to_world is not None else T.identity_affine()
+        r = lib().hrth_scene_load_mesh_instance(self._h, *mesh.ptrs(), C.byref(m))
+        if r < 0:
+            raise ValueError("load_mesh_instance: invalid mesh arrays")
+        return r
+
+    def rebuild_tlas(self):
+        """Scene.RebuildTLAS (Scene.cs:358-368)."""
+        lib().hrth_scene_rebuild_tlas(self._h)
+
+    def desc(self):
+        d = T.SceneDesc()
+        lib().hrth_scene_get_desc(self._h, C.byref(d))
+        return d
+
+    def arrays(self):
+        return T.arrays_from_scene_desc(self.desc())
+
+
+# ------------------------------------------------------------------ RTRenderer (Engine/RTRenderer.cs)
+class RTRenderer:
+    """Frame orchestration of RTRenderer.RenderDirectToPbo up to the end-of-frame Synchronize
+    (RTRenderer.cs:105-205,233).  Presentation (PBO map, TAAU/blit) is out of scope."""
+
+    def __init__(self, device_ids=None, width=1280, height=720, build_default_scene=False):
+        L = lib()
+        ids = list(device_ids) if device_ids is not None else [0]
+        arr = (C.c_int * len(ids))(*ids)
+        h = C.c_void_p()
+        rc = L.hrt_create(arr, len(ids), C.byref(h))
+        if rc != 0:
+            raise HrtError(rc, (L.hrt_last_error(None) or b"").decode())
+        self._ctx = h
+        self.n_devices = len(ids)
+        # private fields of the reference's RTRenderer (RTRenderer.cs:43-61), same defaults except
+        # render scale (benchmarks render at 1.0) -- callers set what they need
+        self.enable_temporal_reuse = 1
+        self.enable_spatial_reuse = 1
+        self.rng_lock_noise = 1
+        self.spp = 2
+        self.max_depth = 3
+        self.sun_azimuth = 0.0
+        self.sun_elevation = 0.9
+        self.sun_speed = 0.0
+        self.dir_light_radiance = (10.0, 10.0, 10.0)
+        self.sky_tint_top = (0.5, 0.7, 1.0)
+        self.sky_tint_bottom = (1.0, 1.0, 1.0)
+        self.camera = create_camera(max(1, width), max(1, height), 60.0)
+        camera_translate(self.camera, (1.0, 0.0, -4.0))           # RTRenderer.cs:78-79
+        self.prev_camera = copy_camera(self.camera)
+        self.scene = None
+        self.last_params = None
+        if build_default_scene:
+            s = Scene()
+            s.build_default_scene()
+            self.commit(s)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib().hrt_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise HrtError(rc, (lib().hrt_last_error(self._ctx) or b"").decode())
+
+    def commit(self, scene_or_desc):
+        """SceneManager.Commit -> BvhManager.BuildOrRefit -> Scene.UploadAll."""
+        if isinstance(scene_or_desc, T.SceneDesc):
+            d = scene_or_desc
+        else:
+            self.scene = scene_or_desc
+            d = scene_or_desc.desc()
+        self._check(lib().hrt_scene_upload(self._ctx, C.byref(d)))
+
+    def set_sun_params(self, speed_rad_per_sec, elevation_rad):
+        """RTRenderer.SetSunParams (RTRenderer.cs:99-103)."""
+        self.sun_speed = speed_rad_per_sec
+        self.sun_elevation = elevation_rad
+
+    def make_params(self, width, height, frame, dt=0.0):
+        """Parameter assembly of RenderDirectToPbo (RTRenderer.cs:109-202) at render scale 1."""
+        w, h = max(1, width), max(1, height)
+        bake_camera_derived(self.camera, w, h)
+        bake_camera_derived(self.prev_camera, w, h)
+        temporal_seed = 0 if self.rng_lock_noise == 0 else random.randint(-2 ** 31, 2 ** 31 - 2)
+        dtc = min(max(dt, 0.0), 0.1)
+        self.sun_azimuth += self.sun_speed * dtc
+        two_pi = 6.28318530717958647692
+        if self.sun_azimuth >= two_pi:
+            self.sun_azimuth -= two_pi
+        elif self.sun_azimuth < 0.0:
+            self.sun_azimuth += two_pi
+        p = T.FrameParams()
+        p.width, p.height, p.frame = w, h, frame
+        p.cam = copy_camera(self.camera)
+        p.prevCam = copy_camera(self.prev_camera)
+        p.dirLightDir = T.f3(*sun_direction(self.sun_azimuth, self.sun_elevation))
+        p.dirLightRadiance = T.f3(*self.dir_light_radiance)
+        p.skyTintTop = T.f3(*self.sky_tint_top)
+        p.skyTintBottom = T.f3(*self.sky_tint_bottom)
+        p.debugCamSeq = 0
+        p.enableTemporalReuse = self.enable_temporal_reuse
+        p.enableSpatialReuse = self.enable_spatial_reuse
+        p.rngLockNoise = temporal_seed
+        p.spp = self.spp
+        p.maxDepth = self.max_depth
+        return p
+
+    def render_params(self, params, outputs=None, flags=0, rows=None):
+        """The two launches + sync for an explicit FrameParams.  Returns Stats."""
+        st = T.Stats()
+        opts = T.RenderOpts(flags, rows[0] if rows else 0, rows[1] if rows else 0)
+        self._check(lib().hrt_render_frame(self._ctx, C.byref(params), C.byref(opts),
+                                           C.byref(outputs) if outputs is not None else None, C.byref(st)))
+        self.last_params = params
+        return st
+
+    def render_frame(self, width, height, frame, dt=0.0, outputs=None, flags=0, rows=None):
+        """RenderDirectToPbo(pbo, width, height, frame, dt) without the presentation step."""
+        p = self.make_params(width, height, frame, dt)
+        st = self.render_params(p, outputs, flags, rows)
+        self.prev_camera = copy_camera(self.camera)             # RTRenderer.cs:236
+        return st
+
+    def reset_history(self):
+        self._check(lib().hrt_reset_history(self._ctx))
+
+    def device_views(self, slot=0):
+        v = T.DeviceViews()
+        self._check(lib().hrt_device_buffers(self._ctx, slot, C.byref(v)))
+        return v
+
+    def math_probe(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        yy = np.ascontiguousarray(y, dtype=np.float32) if y is not None else None
+        self._check(lib().hrt_math_probe(self._ctx, fn, x.size, x.ctypes.data, yy.ctypes.data if yy is not None else None, out.ctypes.data))
+        return out
+
+
+def device_count():
+    return lib().hrt_device_count()

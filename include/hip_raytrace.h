@@ -1,0 +1,145 @@
+/*
+ * hip_raytrace.h -- C ABI of libhip_raytrace.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for ONE path of NullandKale/ILGPU_Raytracing: the two ILGPU kernel
+ * launches inside RTRenderer.RenderDirectToPbo and the device buffers they touch.
+ * Plain pointers and sizes only; no C++ or torch types.  The reference-side binding a
+ * maintainer adds (C# [DllImport]) is shown in INTEGRATION.md.
+ *
+ *   entry point            replaces in the reference (ILGPU_Raytracing/Engine/...)
+ *   ---------------------  -----------------------------------------------------------
+ *   hrt_create             Context.Create + CreateCudaAccelerator + DefaultStream,
+ *                          LoadAutoGroupedStreamKernel x2        RTRenderer.cs:66-68,85-86
+ *   hrt_scene_upload       Scene.UploadAll (15 Allocate1D H2D copies, empty -> 1 zeroed
+ *                          element)                              Scene.cs:258-279,370-377
+ *                          reached through SceneManager.Commit / BvhManager.BuildOrRefit
+ *                                                                SceneManager.cs:23, BvhManager.cs:27
+ *   hrt_render_frame       GBuffer.EnsureLength / Framebuffer.EnsureLength /
+ *                          EnsureLowResBuffers                   RTRenderer.cs:118-120,265-279
+ *                          _primaryKernel(Index1D(inLen), gp)    RTRenderer.cs:152-153
+ *                          Framebuffer.GetReservoirPair(0,frame) RTRenderer.cs:164, Framebuffer.cs:127-146
+ *                          _integratorKernel(Index1D(inLen), ip, SpecializedValue(maxDepth))
+ *                                                                RTRenderer.cs:181-205
+ *                          _cuda.Synchronize()                   RTRenderer.cs:233
+ *                          Framebuffer.DownloadToCpu (the unused read-back hook)
+ *                                                                Framebuffer.cs:148-160
+ *   hrt_device_buffers     GpuFramebuffer / GpuGBuffer views handed to the post kernels
+ *                          (TAAU, blit) without leaving the device  RTRenderer.cs:155-161,208-231
+ *   hrt_reset_history      Framebuffer.EnsureLength re-allocation on resize (fresh
+ *                          reservoirs)                           Framebuffer.cs:60-97
+ *   hrt_destroy            RTRenderer.Dispose                    RTRenderer.cs:347-363
+ *   hrt_last_error         the exception message of CudaException / Argument*Exception
+ *
+ * Behavioural contract kept from the reference:
+ *   - frame parity picks the reservoir pair: even frame -> prev = B, cur = A
+ *     (Framebuffer.cs:132-145); reservoirs are zero-initialised when (re)allocated
+ *     (the reference leaves them uninitialised; zero makes frame 0 well defined:
+ *      m == 0 rejects every import, RTRay.cs:417).
+ *   - per-pixel buffers are re-allocated only when width*height changes.
+ *   - RNG and ReSTIR hashing key on the GLOBAL pixel index, so tiling never changes a
+ *     pixel's value (RTUtils.cs:108-113, RTRay.cs:488).
+ *   - hrt_render_frame blocks until the frame is complete; one call at a time per ctx.
+ *
+ * Multi-GPU: a ctx created on n devices splits the image into n contiguous row blocks
+ * (scene replicated, no collective, per-tile hipMemcpyAsync gather into the caller's
+ * host framebuffer).  One-process-per-GPU hosts instead create one ctx per process and
+ * restrict it to a row range with hrt_render_opts.row_begin/row_end.
+ *
+ * Status codes: 0 = ok, negative = error (message via hrt_last_error).
+ */
+#ifndef HIP_RAYTRACE_H
+#define HIP_RAYTRACE_H
+
+#include "hrt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hrt_ctx hrt_ctx;
+
+enum hrt_status {
+    HRT_OK                = 0,
+    HRT_ERR_INVALID_ARG   = -1,   /* ArgumentNullException / ArgumentOutOfRangeException */
+    HRT_ERR_INVALID_STATE = -2,   /* InvalidOperationException (e.g. render before upload) */
+    HRT_ERR_HIP           = -3,   /* CudaException analogue: a HIP runtime call failed     */
+    HRT_ERR_NO_DEVICE     = -4,
+    HRT_ERR_OUT_OF_MEMORY = -5
+};
+
+enum hrt_render_flags {
+    HRT_FLAG_COUNTERS     = 1u << 0,  /* run the counting build of both kernels, fill hrt_stats.k[] */
+    HRT_FLAG_SKIP_PRIMARY = 1u << 1,  /* bench/profiling only: reuse the resident G-buffer          */
+    HRT_FLAG_REFERENCE_KERNELS = 1u << 2 /* run the literal-layout kernels (A/B baseline, same results) */
+};
+
+/* Host destinations of one frame; any pointer may be NULL (not copied).  Arrays hold
+ * width*height elements in the reference's layout (row 0 = bottom row, RTRay.cs:122).
+ * With a row range only rows [row_begin,row_end) of each array are written. */
+typedef struct hrt_outputs {
+    /* GpuFramebuffer, RTRay.cs:51-56 */
+    int32_t*    color;        /* packed 0xFFRRGGBB                              */
+    float*      depth;
+    int32_t*    objectId;
+    int32_t*    cameraId;     /* 1 element                                      */
+    /* pre-pack Lout (RTRay.cs:323), 3 floats per pixel: the 1e-4 parity target */
+    hrt_float3* radiance;
+    /* GpuGBuffer, RTRay.cs:80-87 */
+    hrt_float3* gb_worldPos;
+    hrt_float3* gb_normalWS;
+    hrt_float3* gb_baseColor;
+    int32_t*    gb_matId;
+    int32_t*    gb_objId;
+    int32_t*    gb_hitMask;
+    /* resCur of this frame, GpuReservoirSoA RTRay.cs:23-31 */
+    hrt_float3* res_L;
+    hrt_float3* res_wi;
+    float*      res_pdf;
+    float*      res_w;
+    float*      res_wSum;
+    int32_t*    res_m;
+    int32_t*    res_lightId;
+} hrt_outputs;
+
+typedef struct hrt_render_opts {
+    uint32_t flags;           /* hrt_render_flags                                   */
+    int32_t  row_begin;       /* rows [row_begin,row_end) of the global image;      */
+    int32_t  row_end;         /* 0,0 = all rows                                     */
+} hrt_render_opts;
+
+/* Device-resident views of the current frame on device slot `dev` (for on-device
+ * consumers such as the TAAU/blit kernels or a torch tensor wrapper).  Pointers stay
+ * valid until the next hrt_render_frame with a different size, or hrt_destroy.
+ * Device arrays cover only that device's rows: element 0 is pixel (0,row_begin). */
+typedef struct hrt_device_views {
+    int32_t row_begin, row_end, width, device_id;
+    void *color, *depth, *objectId, *radiance;
+    void *gb_worldPos, *gb_normalWS, *gb_baseColor, *gb_matId, *gb_objId, *gb_hitMask;
+} hrt_device_views;
+
+int  hrt_create(const int* device_ids, int n_dev, hrt_ctx** out);
+void hrt_destroy(hrt_ctx* ctx);
+const char* hrt_last_error(hrt_ctx* ctx);      /* ctx may be NULL: last error of hrt_create */
+
+int  hrt_scene_upload(hrt_ctx* ctx, const hrt_scene_desc* scene);
+
+int  hrt_render_frame(hrt_ctx* ctx, const hrt_frame_params* params,
+                      const hrt_render_opts* opts,      /* may be NULL */
+                      const hrt_outputs* outputs,       /* may be NULL: leave results on device */
+                      hrt_stats* stats);                /* may be NULL */
+
+int  hrt_device_buffers(hrt_ctx* ctx, int dev, hrt_device_views* out);
+int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */
+
+/* test hook: evaluates function `fn` of include/hrt_math.h on device slot 0 for n inputs
+ * (fn ids as in tests/test_math_gpu.py); lets the GPU tests check bit-equality of the
+ * arithmetic contract against the oracle.  Not needed by a production host. */
+int  hrt_math_probe(hrt_ctx* ctx, int fn, int n, const float* x, const float* y, float* out);
+
+int  hrt_device_count(void);                    /* visible HIP devices, <0 on error */
+const char* hrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_RAYTRACE_H */

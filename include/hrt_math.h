@@ -1,0 +1,224 @@
+/*
+ * hrt_math.h -- the arithmetic contract of the hot path (binary32, no contraction).
+ *
+ * The reference calls ILGPU.Algorithms XMath.{Sqrt,Rsqrt,Sin,Cos,Tan,Atan,Atan2,Acos,
+ * Floor,Round,Abs,Min,Max,Clamp} (ILGPU 1.5.3, not vendored under /root/reference; call
+ * sites listed in SURVEY.md 8c).  XMath's own transcendental code is not available here,
+ * so results at that boundary are "parity unpinned" against the reference binary.  What
+ * this header pins instead is that the HIP kernels and the CPU oracle evaluate ONE
+ * definition of every such function, built only from IEEE-754 binary32 + - * / sqrt,
+ * compares and int<->float conversions, in one fixed operation order.  Compiled with
+ * -ffp-contract=off on both sides (and correctly rounded device div/sqrt, hipcc's
+ * default), every function returns the same bits on gfx950 and on x86-64, so every
+ * data-dependent branch of the path tracer takes the same side on both.
+ *
+ * Algorithms: Cody-Waite 3-term pi/4 reduction + minimax polynomials for sin/cos/tan,
+ * 2-breakpoint reduction for atan, sqrt-halving for asin/acos (Cephes single-precision
+ * library, S. Moshier, public algorithm; max error ~1-2 ulp on the ranges used here:
+ * sin/cos on [0, 2*pi), tan on (0, pi/2), atan2/acos on unit-vector components).
+ *
+ * min/max: IEEE-754-2008 minNum/maxNum with -0 < +0, i.e. what v_min_f32 / v_max_f32
+ * compute and what PTX min.f32/max.f32 (the reference's real target) compute.
+ */
+#ifndef HRT_MATH_H
+#define HRT_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HRT_HD __host__ __device__ __forceinline__
+#else
+#define HRT_HD static inline __attribute__((always_inline))
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+#define HRT_PI      3.14159265358979323846f
+#define HRT_INV_PI  0.31830988618379067154f
+
+HRT_HD uint32_t hrt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+HRT_HD float    hrt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* ---- min / max -------------------------------------------------------------- */
+HRT_HD float hrt_fmin(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fminf(a, b);                 /* v_min_f32 */
+#else
+    if (a < b) return a;
+    if (b < a) return b;
+    if (a == b) return hrt_u2f(hrt_f2u(a) | hrt_f2u(b));   /* -0 wins */
+    return (a != a) ? b : a;                      /* NaN -> the other operand */
+#endif
+}
+HRT_HD float hrt_fmax(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(a, b);                 /* v_max_f32 */
+#else
+    if (a > b) return a;
+    if (b > a) return b;
+    if (a == b) return hrt_u2f(hrt_f2u(a) & hrt_f2u(b));   /* +0 wins */
+    return (a != a) ? b : a;
+#endif
+}
+HRT_HD int hrt_imin(int a, int b) { return a < b ? a : b; }
+HRT_HD int hrt_imax(int a, int b) { return a > b ? a : b; }
+/* XMath.Clamp(v, lo, hi) = Max(Min(v, hi), lo) */
+HRT_HD float hrt_clamp(float v, float lo, float hi) { return hrt_fmax(hrt_fmin(v, hi), lo); }
+
+/* ---- exactly rounded primitives ---------------------------------------------- */
+HRT_HD float hrt_abs(float x)   { return __builtin_fabsf(x); }
+HRT_HD float hrt_sqrt(float x)  { return __builtin_sqrtf(x); }      /* IEEE correctly rounded */
+HRT_HD float hrt_rsqrt(float x) { return 1.0f / __builtin_sqrtf(x); } /* XMath.Rsqrt on CPU = 1/Sqrt */
+HRT_HD float hrt_floor(float x) { return __builtin_floorf(x); }
+HRT_HD float hrt_round(float x) { return __builtin_rintf(x); }      /* XMath.Round: half-to-even */
+
+/* ---- sin / cos / tan ----------------------------------------------------------- */
+#define HRT_FOPI 1.27323954473516f              /* 4/pi */
+#define HRT_DP1  0.78515625f
+#define HRT_DP2  2.4187564849853515625e-4f
+#define HRT_DP3  3.77489497744594108e-8f
+
+HRT_HD float hrt__sin_poly(float x, float z)
+{
+    return ((-1.9515295891E-4f * z + 8.3321608736E-3f) * z - 1.6666654611E-1f) * z * x + x;
+}
+HRT_HD float hrt__cos_poly(float z)
+{
+    float y = ((2.443315711809948E-005f * z - 1.388731625493765E-003f) * z
+               + 4.166664568298827E-002f) * z * z;
+    y = y - 0.5f * z;
+    return y + 1.0f;
+}
+
+HRT_HD float hrt_sin(float xin)
+{
+    float sign = 1.0f;
+    float x = xin;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    int j = (int)(HRT_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { sign = -sign; j -= 4; }
+    x = ((x - y * HRT_DP1) - y * HRT_DP2) - y * HRT_DP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? hrt__cos_poly(z) : hrt__sin_poly(x, z);
+    return (sign < 0.0f) ? -r : r;
+}
+
+HRT_HD float hrt_cos(float xin)
+{
+    float sign = 1.0f;
+    float x = xin;
+    if (x < 0.0f) x = -x;
+    int j = (int)(HRT_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    if (j > 3) { j -= 4; sign = -sign; }
+    if (j > 1) sign = -sign;
+    x = ((x - y * HRT_DP1) - y * HRT_DP2) - y * HRT_DP3;
+    float z = x * x;
+    float r = (j == 1 || j == 2) ? hrt__sin_poly(x, z) : hrt__cos_poly(z);
+    return (sign < 0.0f) ? -r : r;
+}
+
+HRT_HD float hrt_tan(float xin)
+{
+    float sign = 1.0f;
+    float x = xin;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    int j = (int)(HRT_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    float z = ((x - y * HRT_DP1) - y * HRT_DP2) - y * HRT_DP3;
+    float zz = z * z;
+    float r;
+    if (x > 1.0e-4f) {
+        r = (((((9.38540185543E-3f * zz + 3.11992232697E-3f) * zz + 2.44301354525E-2f) * zz
+               + 5.34112807005E-2f) * zz + 1.33387994085E-1f) * zz + 3.33331568548E-1f) * zz * z + z;
+    } else {
+        r = z;
+    }
+    if (j & 2) r = -1.0f / r;
+    return (sign < 0.0f) ? -r : r;
+}
+
+/* ---- atan / atan2 / asin / acos ---------------------------------------------------- */
+#define HRT_PIO2 1.5707963267948966192f
+#define HRT_PIO4 0.7853981633974483096f
+
+HRT_HD float hrt_atan(float xin)
+{
+    float sign = 1.0f;
+    float x = xin;
+    if (x < 0.0f) { sign = -1.0f; x = -x; }
+    float y;
+    if (x > 2.414213562373095f)       { y = HRT_PIO2; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = HRT_PIO4; x = (x - 1.0f) / (x + 1.0f); }
+    else                              { y = 0.0f; }
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032E-1f) * z + 1.99777106478E-1f) * z
+              - 3.33329491539E-1f) * z * x + x);
+    return (sign < 0.0f) ? -y : y;
+}
+
+HRT_HD float hrt_atan2(float y, float x)
+{
+    int code = 0;
+    if (x < 0.0f) code = 2;
+    if (y < 0.0f) code |= 1;
+    if (x == 0.0f) {
+        if (code & 1) return -HRT_PIO2;
+        if (y == 0.0f) return 0.0f;
+        return HRT_PIO2;
+    }
+    if (y == 0.0f) return (code & 2) ? HRT_PI : 0.0f;
+    float w = (code == 2) ? HRT_PI : ((code == 3) ? -HRT_PI : 0.0f);
+    return w + hrt_atan(y / x);
+}
+
+HRT_HD float hrt_asin(float xin)
+{
+    float sign = 1.0f;
+    float a = xin;
+    if (a < 0.0f) { sign = -1.0f; a = -a; }
+    if (a > 1.0f) return 0.0f;
+    if (a < 1.0e-4f) return xin;
+    float x, z;
+    int flag = 0;
+    if (a > 0.5f) { z = 0.5f * (1.0f - a); x = hrt_sqrt(z); flag = 1; }
+    else          { x = a; z = x * x; }
+    z = ((((4.2163199048E-2f * z + 2.4181311049E-2f) * z + 4.5470025998E-2f) * z
+          + 7.4953002686E-2f) * z + 1.6666752422E-1f) * z * x + x;
+    if (flag) { z = z + z; z = HRT_PIO2 - z; }
+    return (sign < 0.0f) ? -z : z;
+}
+
+HRT_HD float hrt_acos(float x)
+{
+    if (x < -0.5f) return HRT_PI - 2.0f * hrt_asin(hrt_sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f)  return 2.0f * hrt_asin(hrt_sqrt(0.5f * (1.0f - x)));
+    return HRT_PIO2 - hrt_asin(x);
+}
+
+/* C# (int)x for float x, made total: truncation toward zero inside int range; NaN and
+ * out-of-range give INT_MIN (what cvttss2si returns; v_cvt_i32_f32 would saturate / give 0,
+ * so both sides go through this one definition). */
+HRT_HD int hrt_f2i(float x)
+{
+    if (!(x >= -2147483648.0f && x < 2147483648.0f)) return (int)0x80000000u;
+    return (int)x;
+}
+
+/* double.IsFinite(x) on a float (RTRay.cs:648-650), immune to any NaN folding */
+HRT_HD int hrt_isfinite(float x) { return (hrt_f2u(x) & 0x7F800000u) != 0x7F800000u; }
+
+#endif /* HRT_MATH_H */
