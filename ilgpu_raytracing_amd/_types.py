@@ -108,7 +108,7 @@ class KernelCounters(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("k", KernelCounters * 2), ("kernel_ms", C.c_double * 2), ("d2h_ms", C.c_double),
-                ("n_devices", C.c_int32), ("counters_valid", C.c_int32)]
+                ("n_devices", C.c_int32), ("counters_valid", C.c_int32), ("frames", C.c_int32), ("reserved", C.c_int32)]
 
 
 OUTPUT_ARRAYS = [
@@ -126,18 +126,18 @@ class Outputs(C.Structure):
 
 
 class RenderOpts(C.Structure):
-    _fields_ = [("flags", C.c_uint32), ("row_begin", C.c_int32), ("row_end", C.c_int32)]
+    _fields_ = [("flags", C.c_uint32), ("row_begin", C.c_int32), ("row_end", C.c_int32), ("strip_n", C.c_int32), ("strip_i", C.c_int32)]
 
 
 class DeviceViews(C.Structure):
-    _fields_ = [("row_begin", C.c_int32), ("row_end", C.c_int32), ("width", C.c_int32), ("device_id", C.c_int32)] + \
+    _fields_ = [(n, C.c_int32) for n in ("row_begin", "row_end", "strip_n", "strip_i", "width", "height", "device_id", "reserved")] + \
                [(n, C.c_void_p) for n in ("color", "depth", "objectId", "radiance", "gb_worldPos", "gb_normalWS",
                                           "gb_baseColor", "gb_matId", "gb_objId", "gb_hitMask")]
 
 
 FLAG_COUNTERS = 1
 FLAG_SKIP_PRIMARY = 2
-FLAG_REFERENCE_KERNELS = 4
+FLAG_NO_SYNC = 8
 
 SHADING_LAMBERT, SHADING_MIRROR, SHADING_GLASS = 0, 1, 2
 BLAS_SPHERESET, BLAS_TRIMESH = 1, 2

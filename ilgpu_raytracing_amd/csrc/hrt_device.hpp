@@ -584,7 +584,7 @@ HRT_D bool shadow_occluded(const DScene& S, const Ray& wray, float tMaxWorld, Cn
 // ------------------------------------------------------------------ frame constants
 struct FrameK {          // scalar part of GBufferParams / IntegratorParams (RTRay.cs:112-146)
     int32_t width, height, frame;
-    int32_t row_begin, row_end;
+    int32_t row_begin, row_end, strip_n, strip_i;   // tile: 8-row strips s of [row_begin,row_end) with s % strip_n == strip_i
     hrt_camera cam, prevCam;
     hrt_float3 dirLightDir, dirLightRadiance, skyTop, skyBottom;
     int32_t debugCamSeq, enableTemporal, enableSpatial, rngLockNoise, spp, maxDepth;
@@ -831,11 +831,11 @@ HRT_D void path_trace_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb
         const float gior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
         const F3 gI = normalize(gpos - cv3(k.cam.origin));
         const SeedBase sb = seed_base((uint32_t)px, (uint32_t)py, k.frame, 0xC0FFEEu, k.rngLockNoise);
-        bool wroteReservoir = false;
 
         for (int s = 0; s < spp; s++)
         {
             Rng rng = rng_for_sample(sb, (uint32_t)s);
+            bool wroteReservoir = false;        // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
             F3 pos = gpos, nrm = gnrm, alb = galb, I = gI;
             int shade = gshade; float ior = gior;
             F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);

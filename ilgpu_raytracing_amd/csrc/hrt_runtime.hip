@@ -36,7 +36,7 @@ __device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, i
     int ty = tile / tm.tilesX, tx = tile - ty * tm.tilesX;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     x = tx * 32 + wave * 8 + (lane & 7);
-    y = k.row_begin + ty * 8 + (lane >> 3);
+    y = k.row_begin + (ty * k.strip_n + k.strip_i) * 8 + (lane >> 3);   // 8-row strips dealt round-robin over tiles
     return x < k.width && y < k.row_end;
 }
 
@@ -90,7 +90,10 @@ thread_local std::string g_create_error;
 struct DeviceState {
     int device_id = -1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int kRing = 128;          // frames that may be in flight between two syncs
+    hipEvent_t ev[kRing][4] = {};
+    int ring_head = 0;                         // frames enqueued since the last synchronize
+    bool ring_counts = false;
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
@@ -100,7 +103,9 @@ struct DeviceState {
     DFramebuffer fb{};
     DReservoir resA{}, resB{};
     unsigned long long* counters = nullptr;   // 2 x 10
-    int row_begin = 0, row_end = 0;
+    int row_begin = 0, row_end = 0;            // rows [row_begin,row_end) ...
+    int strip_n = 1, strip_i = 0;              // ... of which this device owns 8-row strips s with s % strip_n == strip_i
+    int n_strips = 0;
 };
 
 } // namespace
@@ -143,26 +148,29 @@ void free_pixels(DeviceState& d)
     d.nPix = 0;
 }
 
-template <class T> hipError_t dalloc(T*& p, int64_t n, bool zero)
+// zero-fill is ordered on the device's own (non-blocking) stream: the null stream does not
+// synchronise with it, so a hipMemset there could land after the first kernel's stores
+template <class T> hipError_t dalloc(T*& p, int64_t n, hipStream_t stream)
 {
     void* v = nullptr;
     hipError_t e = hipMalloc(&v, (size_t)n * sizeof(T));
     if (e != hipSuccess) return e;
-    if (zero) { e = hipMemset(v, 0, (size_t)n * sizeof(T)); if (e != hipSuccess) return e; }
+    e = hipMemsetAsync(v, 0, (size_t)n * sizeof(T), stream);
+    if (e != hipSuccess) return e;
     p = static_cast<T*>(v);
     return hipSuccess;
 }
 
-hipError_t alloc_res(DReservoir& r, int64_t n)
+hipError_t alloc_res(DReservoir& r, int64_t n, hipStream_t st)
 {
     hipError_t e;
-    if ((e = dalloc(r.L, n, true)) != hipSuccess) return e;
-    if ((e = dalloc(r.wi, n, true)) != hipSuccess) return e;
-    if ((e = dalloc(r.pdf, n, true)) != hipSuccess) return e;
-    if ((e = dalloc(r.w, n, true)) != hipSuccess) return e;
-    if ((e = dalloc(r.wSum, n, true)) != hipSuccess) return e;
-    if ((e = dalloc(r.m, n, true)) != hipSuccess) return e;
-    return dalloc(r.lightId, n, true);
+    if ((e = dalloc(r.L, n, st)) != hipSuccess) return e;
+    if ((e = dalloc(r.wi, n, st)) != hipSuccess) return e;
+    if ((e = dalloc(r.pdf, n, st)) != hipSuccess) return e;
+    if ((e = dalloc(r.w, n, st)) != hipSuccess) return e;
+    if ((e = dalloc(r.wSum, n, st)) != hipSuccess) return e;
+    if ((e = dalloc(r.m, n, st)) != hipSuccess) return e;
+    return dalloc(r.lightId, n, st);
 }
 
 // GBuffer.EnsureLength / Framebuffer.EnsureLength / EnsureLowResBuffers: realloc on size change only
@@ -171,19 +179,19 @@ int ensure_pixels(hrt_ctx* c, DeviceState& d, int64_t nPix)
     if (d.nPix == nPix) return HRT_OK;
     HIPCHK(c, hipSetDevice(d.device_id));
     free_pixels(d);
-    HIPCHK(c, dalloc(d.gb.worldPos, nPix, true));
-    HIPCHK(c, dalloc(d.gb.normalWS, nPix, true));
-    HIPCHK(c, dalloc(d.gb.baseColor, nPix, true));
-    HIPCHK(c, dalloc(d.gb.matId, nPix, true));
-    HIPCHK(c, dalloc(d.gb.objId, nPix, true));
-    HIPCHK(c, dalloc(d.gb.hitMask, nPix, true));
-    HIPCHK(c, dalloc(d.fb.color, nPix, true));
-    HIPCHK(c, dalloc(d.fb.depth, nPix, true));
-    HIPCHK(c, dalloc(d.fb.objectId, nPix, true));
-    HIPCHK(c, dalloc(d.fb.cameraId, 1, true));
-    HIPCHK(c, dalloc(d.fb.radiance, nPix, true));
-    HIPCHK(c, alloc_res(d.resA, nPix));
-    HIPCHK(c, alloc_res(d.resB, nPix));
+    HIPCHK(c, dalloc(d.gb.worldPos, nPix, d.stream));
+    HIPCHK(c, dalloc(d.gb.normalWS, nPix, d.stream));
+    HIPCHK(c, dalloc(d.gb.baseColor, nPix, d.stream));
+    HIPCHK(c, dalloc(d.gb.matId, nPix, d.stream));
+    HIPCHK(c, dalloc(d.gb.objId, nPix, d.stream));
+    HIPCHK(c, dalloc(d.gb.hitMask, nPix, d.stream));
+    HIPCHK(c, dalloc(d.fb.color, nPix, d.stream));
+    HIPCHK(c, dalloc(d.fb.depth, nPix, d.stream));
+    HIPCHK(c, dalloc(d.fb.objectId, nPix, d.stream));
+    HIPCHK(c, dalloc(d.fb.cameraId, 1, d.stream));
+    HIPCHK(c, dalloc(d.fb.radiance, nPix, d.stream));
+    HIPCHK(c, alloc_res(d.resA, nPix, d.stream));
+    HIPCHK(c, alloc_res(d.resB, nPix, d.stream));
     d.nPix = nPix;
     return HRT_OK;
 }
@@ -196,11 +204,28 @@ void free_scene(DeviceState& d)
 template <class T>
 int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
 {
-    if (!host) return HRT_OK;
-    size_t off = (size_t)d.row_begin * width;
-    size_t cnt = (size_t)(d.row_end - d.row_begin) * width;
-    if (cnt == 0) return HRT_OK;
-    HIPCHK(c, hipMemcpyAsync(host + off, devp + off, cnt * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+    if (!host || d.n_strips == 0) return HRT_OK;
+    const size_t rowElems = (size_t)width;
+    if (d.strip_n == 1)
+    {   // one contiguous row block
+        size_t off = (size_t)d.row_begin * rowElems;
+        size_t cnt = (size_t)(d.row_end - d.row_begin) * rowElems;
+        HIPCHK(c, hipMemcpyAsync(host + off, devp + off, cnt * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+        return HRT_OK;
+    }
+    // interleaved 8-row strips: one strided 2-D copy for the full strips, one plain copy for a ragged last strip
+    int lastStrip = d.strip_i + (d.n_strips - 1) * d.strip_n;
+    int lastRows = std::min(8, (d.row_end - d.row_begin) - lastStrip * 8);
+    int fullStrips = lastRows == 8 ? d.n_strips : d.n_strips - 1;
+    size_t first = ((size_t)d.row_begin + (size_t)d.strip_i * 8) * rowElems;
+    if (fullStrips > 0)
+        HIPCHK(c, hipMemcpy2DAsync(host + first, (size_t)8 * rowElems * d.strip_n * sizeof(T), devp + first, (size_t)8 * rowElems * d.strip_n * sizeof(T),
+                                   (size_t)8 * rowElems * sizeof(T), (size_t)fullStrips, hipMemcpyDeviceToHost, d.stream));
+    if (lastRows < 8 && lastRows > 0)
+    {
+        size_t off = ((size_t)d.row_begin + (size_t)lastStrip * 8) * rowElems;
+        HIPCHK(c, hipMemcpyAsync(host + off, devp + off, (size_t)lastRows * rowElems * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+    }
     return HRT_OK;
 }
 
@@ -208,7 +233,7 @@ int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
 
 extern "C" {
 
-const char* hrt_version(void) { return "hip_raytrace 0.1 (gfx950)"; }
+const char* hrt_version(void) { return "hip_raytrace 0.2 (gfx950)"; }
 
 int hrt_device_count(void)
 {
@@ -226,7 +251,7 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
     int avail = 0;
     hipError_t e = hipGetDeviceCount(&avail);
     if (e != hipSuccess || avail <= 0)
-        return fail(nullptr, HRT_ERR_NO_DEVICE, std::string("hrt_create: no HIP device (") + hipGetErrorString(e) + ")");
+        return fail(nullptr, HRT_ERR_NO_DEVICE, std::string("hrt_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU path");
     std::vector<int> ids;
     if (device_ids && n_dev > 0) ids.assign(device_ids, device_ids + n_dev);
     else ids.push_back(0);
@@ -240,7 +265,8 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
         d.device_id = ids[i];
         hipError_t err = hipSetDevice(d.device_id);
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
-        for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[k]);
+        for (int f = 0; f < DeviceState::kRing && err == hipSuccess; f++)
+            for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[f][k]);
         if (err == hipSuccess) { void* p = nullptr; err = hipMalloc(&p, 20 * sizeof(unsigned long long)); d.counters = (unsigned long long*)p; }
         if (err != hipSuccess)
         {
@@ -264,10 +290,50 @@ void hrt_destroy(hrt_ctx* c)
         free_pixels(d);
         free_scene(d);
         if (d.counters) (void)hipFree(d.counters);
-        for (int k = 0; k < 4; k++) if (d.ev[k]) (void)hipEventDestroy(d.ev[k]);
+        for (int f = 0; f < DeviceState::kRing; f++)
+            for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete c;
+}
+
+int hrt_synchronize(hrt_ctx* c, hrt_stats* stats)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    hrt_stats st; std::memset(&st, 0, sizeof(st));
+    st.n_devices = (int)c->dev.size();
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        HIPCHK(c, hipStreamSynchronize(d.stream));        // _cuda.Synchronize(), RTRenderer.cs:233
+        double k0 = 0, k1 = 0, dh = 0;
+        for (int f = 0; f < d.ring_head; f++)
+        {
+            float ms;
+            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][0], d.ev[f][1])); k0 += ms;
+            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][1], d.ev[f][2])); k1 += ms;
+            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][2], d.ev[f][3])); dh += ms;
+        }
+        st.kernel_ms[0] = std::max(st.kernel_ms[0], k0);
+        st.kernel_ms[1] = std::max(st.kernel_ms[1], k1);
+        st.d2h_ms = std::max(st.d2h_ms, dh);
+        st.frames = std::max(st.frames, d.ring_head);
+        if (d.ring_counts)
+        {
+            unsigned long long h[20];
+            HIPCHK(c, hipMemcpy(h, d.counters, sizeof(h), hipMemcpyDeviceToHost));
+            for (int kk = 0; kk < 2; kk++)
+            {
+                uint64_t* dst = reinterpret_cast<uint64_t*>(&st.k[kk]);
+                for (int i = 0; i < 10; i++) dst[i] += h[kk * 10 + i];
+            }
+            st.counters_valid = 1;
+        }
+        d.ring_head = 0;
+        d.ring_counts = false;
+    }
+    if (stats) *stats = st;
+    return HRT_OK;
 }
 
 int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
@@ -282,19 +348,20 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
                              s->n_materials, s->n_texels, s->n_texInfos};
     for (int i = 0; i < 15; i++)
         if (cnt[i] < 0 || (cnt[i] > 0 && !src[i])) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: array " + std::to_string(i) + " has a count but no pointer");
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
     c->scene_ready = false;
     for (DeviceState& d : c->dev)
     {
         HIPCHK(c, hipSetDevice(d.device_id));
-        HIPCHK(c, hipStreamSynchronize(d.stream));
         free_scene(d);                                  // UploadAll disposes + reallocates all 15 (Scene.cs:260-278)
         for (int i = 0; i < 15; i++)
         {
             int64_t n = cnt[i] > 0 ? cnt[i] : 1;       // AllocateOrEmpty: empty -> 1 zeroed element
             size_t bytes = (size_t)n * kSceneElem[i];
             HIPCHK(c, hipMalloc(&d.scene[i], bytes));
-            if (cnt[i] > 0) HIPCHK(c, hipMemcpy(d.scene[i], src[i], bytes, hipMemcpyHostToDevice));
-            else HIPCHK(c, hipMemset(d.scene[i], 0, bytes));
+            if (cnt[i] > 0) HIPCHK(c, hipMemcpyAsync(d.scene[i], src[i], bytes, hipMemcpyHostToDevice, d.stream));
+            else HIPCHK(c, hipMemsetAsync(d.scene[i], 0, bytes, d.stream));
         }
         DScene& S = d.dscene;
         S.tlasNodes = (const hrt_bvh_node*)d.scene[0]; S.tlasInst = (const int32_t*)d.scene[1];
@@ -306,6 +373,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         S.materials = (const hrt_material*)d.scene[12]; S.texels = (const hrt_rgba32*)d.scene[13];
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
+        HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;
     return HRT_OK;
@@ -314,6 +382,8 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
 int hrt_reset_history(hrt_ctx* c)
 {
     if (!c) return HRT_ERR_INVALID_ARG;
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
     for (DeviceState& d : c->dev)
     {
         if (d.nPix == 0) continue;
@@ -339,27 +409,26 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     if (p->width <= 0 || p->height <= 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: width/height must be positive");
     if ((int64_t)p->width * p->height > 0x7FFFFFFFLL) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: image too large for int pixel indices");
     if (p->maxDepth < 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: maxDepth must be >= 0");
-    uint32_t flags = opts ? opts->flags : 0u;
+    const uint32_t flags = opts ? opts->flags : 0u;
     int rb = opts ? opts->row_begin : 0, re = opts ? opts->row_end : 0;
+    int sn = opts && opts->strip_n > 0 ? opts->strip_n : 1, si = opts ? opts->strip_i : 0;
     if (rb == 0 && re == 0) re = p->height;
     if (rb < 0 || re > p->height || rb > re) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: row range outside the image");
+    if (si < 0 || si >= sn) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: strip_i must be in [0, strip_n)");
+    const bool nosync = (flags & HRT_FLAG_NO_SYNC) != 0;
+    if (nosync && out) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: HRT_FLAG_NO_SYNC frames cannot gather to host (outputs must be NULL)");
     const bool reuse = (p->enableTemporalReuse != 0 || p->enableSpatialReuse != 0);
     const int nd = (int)c->dev.size();
-    if (reuse && (nd > 1 || rb != 0 || re != p->height))
+    if (reuse && (nd > 1 || sn > 1 || rb != 0 || re != p->height))
         return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse across row tiles needs the G-buffer/reservoir exchange step (not built yet); render reuse frames on one full-image tile");
     const int64_t nPix = (int64_t)p->width * p->height;
     const bool count = (flags & HRT_FLAG_COUNTERS) != 0;
 
-    // contiguous row blocks, 8-row granularity so wave tiles never straddle two devices
-    int rows = re - rb;
-    int units = (rows + 7) / 8;
-    for (int i = 0; i < nd; i++)
-    {
-        int u0 = (int)((int64_t)units * i / nd), u1 = (int)((int64_t)units * (i + 1) / nd);
-        c->dev[i].row_begin = std::min(re, rb + u0 * 8);
-        c->dev[i].row_end = std::min(re, rb + u1 * 8);
+    if (nPix != c->dev[0].nPix || c->dev[0].ring_head >= DeviceState::kRing)
+    {   // resize (or a full event ring) drains the frames in flight first
+        int rc = hrt_synchronize(c, nullptr);
+        if (rc != HRT_OK) return rc;
     }
-
     for (DeviceState& d : c->dev)
     {
         int rc = ensure_pixels(c, d, nPix);
@@ -367,12 +436,24 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     }
     c->width = p->width; c->height = p->height;
 
+    // 8-row strips of [rb,re) are dealt round-robin: this call owns strips s % sn == si, and
+    // device i of the ctx takes every nd-th of those (sky rows are cheap, geometry rows are
+    // expensive: interleaving balances the tiles without knowing the image)
+    const int S = (re - rb + 7) / 8;
+    for (int i = 0; i < nd; i++)
+    {
+        DeviceState& d = c->dev[i];
+        d.row_begin = rb; d.row_end = re;
+        d.strip_n = sn * nd; d.strip_i = si + sn * i;
+        d.n_strips = d.strip_i < S ? (S - d.strip_i + d.strip_n - 1) / d.strip_n : 0;
+    }
+
     for (DeviceState& d : c->dev)
     {
         HIPCHK(c, hipSetDevice(d.device_id));
         FrameK k;
         k.width = p->width; k.height = p->height; k.frame = p->frame;
-        k.row_begin = d.row_begin; k.row_end = d.row_end;
+        k.row_begin = d.row_begin; k.row_end = d.row_end; k.strip_n = d.strip_n; k.strip_i = d.strip_i;
         k.cam = p->cam; k.prevCam = p->prevCam;
         k.dirLightDir = p->dirLightDir; k.dirLightRadiance = p->dirLightRadiance;
         k.skyTop = p->skyTintTop; k.skyBottom = p->skyTintBottom;
@@ -381,31 +462,35 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
 
         TileMap tm;
         tm.tilesX = (p->width + 31) / 32;
-        tm.tilesY = (d.row_end - d.row_begin + 7) / 8;
+        tm.tilesY = d.n_strips;
         tm.nTiles = tm.tilesX * tm.tilesY;
-        if (count) HIPCHK(c, hipMemsetAsync(d.counters, 0, 20 * sizeof(unsigned long long), d.stream));
+        if (count)
+        {
+            if (d.ring_head > 0 && !d.ring_counts) { int rc = hrt_synchronize(c, nullptr); if (rc != HRT_OK) return rc; HIPCHK(c, hipSetDevice(d.device_id)); }
+            if (!d.ring_counts) HIPCHK(c, hipMemsetAsync(d.counters, 0, 20 * sizeof(unsigned long long), d.stream));
+            d.ring_counts = true;
+        }
         // Framebuffer.GetReservoirPair: even frame -> prev = B, cur = A (Framebuffer.cs:132-145)
         const bool even = (p->frame & 1) == 0;
         DReservoir resPrev = even ? d.resB : d.resA;
         DReservoir resCur = even ? d.resA : d.resB;
-        DFramebuffer fb = d.fb;
-        if (d.device_id != c->dev[0].device_id || d.row_begin != 0) { /* cameraId[0] is written by pixel 0's owner only */ }
+        hipEvent_t* ev = d.ev[d.ring_head];
 
-        HIPCHK(c, hipEventRecord(d.ev[0], d.stream));
+        HIPCHK(c, hipEventRecord(ev[0], d.stream));
         if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
         {
             if (count) hipLaunchKernelGGL(hrt_primary_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
             else       hipLaunchKernelGGL(hrt_primary_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
             HIPCHK(c, hipGetLastError());
         }
-        HIPCHK(c, hipEventRecord(d.ev[1], d.stream));
+        HIPCHK(c, hipEventRecord(ev[1], d.stream));
         if (tm.nTiles > 0)
         {
-            if (count) hipLaunchKernelGGL(hrt_path_trace_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
-            else       hipLaunchKernelGGL(hrt_path_trace_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
+            if (count) hipLaunchKernelGGL(hrt_path_trace_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
+            else       hipLaunchKernelGGL(hrt_path_trace_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
             HIPCHK(c, hipGetLastError());
         }
-        HIPCHK(c, hipEventRecord(d.ev[2], d.stream));
+        HIPCHK(c, hipEventRecord(ev[2], d.stream));
 
         if (out)
         {   // per-tile gather into the caller's host framebuffer
@@ -419,35 +504,14 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
             G(out->res_L, resCur.L); G(out->res_wi, resCur.wi); G(out->res_pdf, resCur.pdf); G(out->res_w, resCur.w);
             G(out->res_wSum, resCur.wSum); G(out->res_m, resCur.m); G(out->res_lightId, resCur.lightId);
 #undef G
-            if (out->cameraId && d.row_begin == 0 && d.row_end > 0)
+            if (out->cameraId && d.row_begin == 0 && d.strip_i == 0 && d.n_strips > 0)
                 HIPCHK(c, hipMemcpyAsync(out->cameraId, d.fb.cameraId, 4, hipMemcpyDeviceToHost, d.stream));
         }
-        HIPCHK(c, hipEventRecord(d.ev[3], d.stream));
+        HIPCHK(c, hipEventRecord(ev[3], d.stream));
+        d.ring_head++;
     }
-
-    hrt_stats st; std::memset(&st, 0, sizeof(st));
-    st.n_devices = nd; st.counters_valid = count ? 1 : 0;
-    for (DeviceState& d : c->dev)
-    {
-        HIPCHK(c, hipSetDevice(d.device_id));
-        HIPCHK(c, hipStreamSynchronize(d.stream));        // _cuda.Synchronize(), RTRenderer.cs:233
-        float ms;
-        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[0], d.ev[1])); st.kernel_ms[0] = std::max(st.kernel_ms[0], (double)ms);
-        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[1], d.ev[2])); st.kernel_ms[1] = std::max(st.kernel_ms[1], (double)ms);
-        HIPCHK(c, hipEventElapsedTime(&ms, d.ev[2], d.ev[3])); st.d2h_ms = std::max(st.d2h_ms, (double)ms);
-        if (count)
-        {
-            unsigned long long h[20];
-            HIPCHK(c, hipMemcpy(h, d.counters, sizeof(h), hipMemcpyDeviceToHost));
-            for (int kk = 0; kk < 2; kk++)
-            {
-                uint64_t* dst = reinterpret_cast<uint64_t*>(&st.k[kk]);
-                for (int i = 0; i < 10; i++) dst[i] += h[kk * 10 + i];
-            }
-        }
-    }
-    if (stats) *stats = st;
-    return HRT_OK;
+    if (nosync) { if (stats) std::memset(stats, 0, sizeof(*stats)); return HRT_OK; }
+    return hrt_synchronize(c, stats);
 }
 
 int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
@@ -456,11 +520,11 @@ int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
     if (dev < 0 || dev >= (int)c->dev.size()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_device_buffers: device slot out of range");
     DeviceState& d = c->dev[dev];
     if (d.nPix == 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_device_buffers: no frame rendered yet");
-    size_t off = (size_t)d.row_begin * c->width;
-    o->row_begin = d.row_begin; o->row_end = d.row_end; o->width = c->width; o->device_id = d.device_id;
-    o->color = d.fb.color + off; o->depth = d.fb.depth + off; o->objectId = d.fb.objectId + off; o->radiance = d.fb.radiance + off;
-    o->gb_worldPos = d.gb.worldPos + off; o->gb_normalWS = d.gb.normalWS + off; o->gb_baseColor = d.gb.baseColor + off;
-    o->gb_matId = d.gb.matId + off; o->gb_objId = d.gb.objId + off; o->gb_hitMask = d.gb.hitMask + off;
+    o->row_begin = d.row_begin; o->row_end = d.row_end; o->strip_n = d.strip_n; o->strip_i = d.strip_i;
+    o->width = c->width; o->height = c->height; o->device_id = d.device_id; o->reserved = 0;
+    o->color = d.fb.color; o->depth = d.fb.depth; o->objectId = d.fb.objectId; o->radiance = d.fb.radiance;
+    o->gb_worldPos = d.gb.worldPos; o->gb_normalWS = d.gb.normalWS; o->gb_baseColor = d.gb.baseColor;
+    o->gb_matId = d.gb.matId; o->gb_objId = d.gb.objId; o->gb_hitMask = d.gb.hitMask;
     return HRT_OK;
 }
 

@@ -51,6 +51,7 @@ def lib():
         L.hrt_last_error.restype = C.c_char_p
         L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
+        L.hrt_synchronize.argtypes = [C.c_void_p, C.POINTER(T.Stats)]
         L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
         L.hrt_reset_history.argtypes = [C.c_void_p]
         L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -299,10 +300,13 @@ class RTRenderer:
         p.maxDepth = self.max_depth
         return p
 
-    def render_params(self, params, outputs=None, flags=0, rows=None):
-        """The two launches + sync for an explicit FrameParams.  Returns Stats."""
+    def render_params(self, params, outputs=None, flags=0, rows=None, strips=None):
+        """The two launches + sync for an explicit FrameParams.  Returns Stats.
+        rows=(y0,y1) restricts the frame to a row range, strips=(n,i) to every n-th 8-row strip of it;
+        flags & FLAG_NO_SYNC only enqueues (collect with synchronize())."""
         st = T.Stats()
-        opts = T.RenderOpts(flags, rows[0] if rows else 0, rows[1] if rows else 0)
+        opts = T.RenderOpts(flags, rows[0] if rows else 0, rows[1] if rows else 0,
+                            strips[0] if strips else 1, strips[1] if strips else 0)
         self._check(lib().hrt_render_frame(self._ctx, C.byref(params), C.byref(opts),
                                            C.byref(outputs) if outputs is not None else None, C.byref(st)))
         self.last_params = params
@@ -313,6 +317,12 @@ class RTRenderer:
         p = self.make_params(width, height, frame, dt)
         st = self.render_params(p, outputs, flags, rows)
         self.prev_camera = copy_camera(self.camera)             # RTRenderer.cs:236
+        return st
+
+    def synchronize(self):
+        """Waits for frames enqueued with FLAG_NO_SYNC; Stats.kernel_ms are sums over Stats.frames frames."""
+        st = T.Stats()
+        self._check(lib().hrt_synchronize(self._ctx, C.byref(st)))
         return st
 
     def reset_history(self):

@@ -23,6 +23,7 @@
  *                          _cuda.Synchronize()                   RTRenderer.cs:233
  *                          Framebuffer.DownloadToCpu (the unused read-back hook)
  *                                                                Framebuffer.cs:148-160
+ *   hrt_synchronize        _cuda.Synchronize() when frames were enqueued without it  RTRenderer.cs:233
  *   hrt_device_buffers     GpuFramebuffer / GpuGBuffer views handed to the post kernels
  *                          (TAAU, blit) without leaving the device  RTRenderer.cs:155-161,208-231
  *   hrt_reset_history      Framebuffer.EnsureLength re-allocation on resize (fresh
@@ -70,7 +71,8 @@ enum hrt_status {
 enum hrt_render_flags {
     HRT_FLAG_COUNTERS     = 1u << 0,  /* run the counting build of both kernels, fill hrt_stats.k[] */
     HRT_FLAG_SKIP_PRIMARY = 1u << 1,  /* bench/profiling only: reuse the resident G-buffer          */
-    HRT_FLAG_REFERENCE_KERNELS = 1u << 2 /* run the literal-layout kernels (A/B baseline, same results) */
+    HRT_FLAG_NO_SYNC      = 1u << 3   /* enqueue only (outputs must be NULL); collect with hrt_synchronize.
+                                         Up to 128 frames may be in flight; the 129th call drains first.      */
 };
 
 /* Host destinations of one frame; any pointer may be NULL (not copied).  Arrays hold
@@ -105,14 +107,18 @@ typedef struct hrt_render_opts {
     uint32_t flags;           /* hrt_render_flags                                   */
     int32_t  row_begin;       /* rows [row_begin,row_end) of the global image;      */
     int32_t  row_end;         /* 0,0 = all rows                                     */
+    int32_t  strip_n;         /* > 1: the range is cut into 8-row strips and this   */
+    int32_t  strip_i;         /* call renders strips s with s % strip_n == strip_i  */
+                              /* (load-balanced tiling for one-process-per-GPU hosts) */
 } hrt_render_opts;
 
 /* Device-resident views of the current frame on device slot `dev` (for on-device
  * consumers such as the TAAU/blit kernels or a torch tensor wrapper).  Pointers stay
  * valid until the next hrt_render_frame with a different size, or hrt_destroy.
- * Device arrays cover only that device's rows: element 0 is pixel (0,row_begin). */
+ * Every array spans the whole image (global pixel index); only the strips this device
+ * owns (rows [row_begin,row_end), strips s % strip_n == strip_i) hold this frame. */
 typedef struct hrt_device_views {
-    int32_t row_begin, row_end, width, device_id;
+    int32_t row_begin, row_end, strip_n, strip_i, width, height, device_id, reserved;
     void *color, *depth, *objectId, *radiance;
     void *gb_worldPos, *gb_normalWS, *gb_baseColor, *gb_matId, *gb_objId, *gb_hitMask;
 } hrt_device_views;
@@ -127,6 +133,11 @@ int  hrt_render_frame(hrt_ctx* ctx, const hrt_frame_params* params,
                       const hrt_render_opts* opts,      /* may be NULL */
                       const hrt_outputs* outputs,       /* may be NULL: leave results on device */
                       hrt_stats* stats);                /* may be NULL */
+
+/* Waits for every frame enqueued with HRT_FLAG_NO_SYNC.  stats (may be NULL): kernel_ms[]
+ * = per-launch HIP-event time summed over those frames (max over devices), frames = their
+ * number.  A blocking hrt_render_frame is enqueue + hrt_synchronize. */
+int  hrt_synchronize(hrt_ctx* ctx, hrt_stats* stats);
 
 int  hrt_device_buffers(hrt_ctx* ctx, int dev, hrt_device_views* out);
 int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */

@@ -195,7 +195,9 @@ typedef struct hrt_stats {
     double kernel_ms[2];        /* hipEvent time of each launch (max over devices)  */
     double d2h_ms;              /* gather of the requested outputs                   */
     int32_t n_devices;
-    int32_t counters_valid;     /* 1 when the frame ran with HRT_FLAG_COUNTERS       */
+    int32_t counters_valid;     /* 1 when the frame(s) ran with HRT_FLAG_COUNTERS    */
+    int32_t frames;             /* frames covered by kernel_ms / d2h_ms (sums)       */
+    int32_t reserved;
 } hrt_stats;
 
 #endif /* HRT_TYPES_H */

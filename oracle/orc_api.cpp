@@ -66,21 +66,22 @@ void add_counters(hrt_kernel_counters& a, const hrt_kernel_counters& b)
     for (size_t i = 0; i < sizeof(hrt_kernel_counters) / sizeof(uint64_t); i++) pa[i] += pb[i];
 }
 
-// run fn(index, Counters&) over rows [y0,y1) with nthreads workers, dynamic 2-row chunks
+// run fn(index, Counters&) over rows [y0,y1) with nthreads workers, dynamic 128-pixel chunks
 template <class F>
 void parallel_rows(int width, int y0, int y1, int nthreads, hrt_kernel_counters& total, F fn)
 {
     if (nthreads < 1) nthreads = 1;
-    std::atomic<int> next(y0);
+    const long long first = (long long)y0 * width, last = (long long)y1 * width;
+    const int chunk = 128;
+    std::atomic<long long> next(first);
     std::vector<Counters> cs(nthreads);
     auto work = [&](int tid) {
         Counters& C = cs[tid];
         for (;;) {
-            int y = next.fetch_add(2);
-            if (y >= y1) break;
-            int ye = y + 2 < y1 ? y + 2 : y1;
-            for (int yy = y; yy < ye; yy++)
-                for (int x = 0; x < width; x++) fn(yy * width + x, C);
+            long long b = next.fetch_add(chunk);
+            if (b >= last) break;
+            long long e = b + chunk < last ? b + chunk : last;
+            for (long long i = b; i < e; i++) fn((int)i, C);
         }
     };
     if (nthreads == 1) work(0);
