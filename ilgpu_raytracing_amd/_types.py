@@ -137,6 +137,7 @@ class DeviceViews(C.Structure):
 
 FLAG_COUNTERS = 1
 FLAG_SKIP_PRIMARY = 2
+FLAG_REFERENCE_LAYOUT = 4
 FLAG_NO_SYNC = 8
 
 SHADING_LAMBERT, SHADING_MIRROR, SHADING_GLASS = 0, 1, 2

@@ -325,9 +325,15 @@ struct Hit {
     float ior;
 };
 
+// ------------------------------------------------------------------ tracer over the reference's own array layout
+// (44-byte nodes, 144-byte instance records, index indirections).  Handles every scene the
+// boundary accepts; TracerPacked (hrt_trace_packed.hpp) is the fast path for the same walk.
+struct TracerRef {
+    DScene S;
+
 // TraceClosest + TraverseBLAS_* (SceneDeviceViews.cs:30-86,124-237)
 template <bool COUNT>
-HRT_D bool trace_closest(const DScene& S, const Ray& wray, Hit& best, Cnt<COUNT>& C)
+HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
 {
     C.inc(C_RAYS_CLOSEST);
     best.t = 1e30f; best.n = mk3(0.f, 0.f, 0.f); best.albedo = mk3(1.f, 1.f, 1.f); best.objId = -1; best.shade = 0; best.ior = 1.f;
@@ -479,7 +485,7 @@ HRT_D bool trace_closest(const DScene& S, const Ray& wray, Hit& best, Cnt<COUNT>
 
 // ShadowOcclusion + AnyHit_* (SceneDeviceViews.cs:89-121,240-327)
 template <bool COUNT>
-HRT_D bool shadow_occluded(const DScene& S, const Ray& wray, float tMaxWorld, Cnt<COUNT>& C)
+HRT_D bool occluded(const Ray& wray, float tMaxWorld, Cnt<COUNT>& C) const
 {
     C.inc(C_RAYS_SHADOW);
     Tex tex(S);
@@ -580,6 +586,7 @@ HRT_D bool shadow_occluded(const DScene& S, const Ray& wray, float tMaxWorld, Cn
     }
     return false;
 }
+};   // struct TracerRef
 
 // ------------------------------------------------------------------ frame constants
 struct FrameK {          // scalar part of GBufferParams / IntegratorParams (RTRay.cs:112-146)
@@ -775,13 +782,13 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
 
 // ------------------------------------------------------------------ kernel bodies
 // PrimaryVisibilityKernel (RTRay.cs:188-201), one pixel per lane.
-template <bool COUNT>
-HRT_D void primary_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb, int index, Cnt<COUNT>& C)
+template <class TR, bool COUNT>
+HRT_D void primary_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, int index, Cnt<COUNT>& C)
 {
     int x = index % k.width, y = index / k.width;
     Ray wray = primary_ray(k, x, y);
     Hit h;
-    bool hit = trace_closest<COUNT>(S, wray, h, C);
+    bool hit = tr.template closest<COUNT>(wray, h, C);
     if (!hit)
     {   // StoreMiss :100-108
         gb.hitMask[index] = 0;
@@ -804,8 +811,8 @@ HRT_D void primary_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb, i
 
 // PathTraceKernel (RTRay.cs:203-325), one pixel per lane, restructured so that each bounce
 // has one shadow-ray site and one closest-hit site shared by all material branches.
-template <bool COUNT>
-HRT_D void path_trace_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb,
+template <class TR, bool COUNT>
+HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb,
                             const DReservoir& resPrev, const DReservoir& resCur, int64_t nPix, int index, Cnt<COUNT>& C)
 {
     if (index == 0 && fb.cameraId) fb.cameraId[0] = k.debugCamSeq;
@@ -898,7 +905,7 @@ HRT_D void path_trace_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb
                         if (nlSel > 0.f)
                         {
                             Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
-                            if (!shadow_occluded<COUNT>(S, sray, 1e29f, C))
+                            if (!tr.template occluded<COUNT>(sray, 1e29f, C))
                             {
                                 float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
                                 F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
@@ -931,7 +938,7 @@ HRT_D void path_trace_pixel(const DScene& S, const FrameK& k, const DGBuffer& gb
 
                 // TraceNext :659-671 -- the one closest-hit site of the bounce loop
                 Hit h;
-                if (!trace_closest<COUNT>(S, ray, h, C)) { Li = Li + T * sky(k, ray.d); break; }
+                if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); break; }
                 pos = ray.o + ray.d * h.t;
                 nrm = normalize(h.n);
                 alb = h.albedo; shade = h.shade; ior = h.ior;

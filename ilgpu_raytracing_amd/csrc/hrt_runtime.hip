@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include "hrt_device.hpp"
+#include "hrt_trace_packed.hpp"
 #include "../../include/hip_raytrace.h"
 
 using namespace hrt;
@@ -40,24 +41,29 @@ __device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, i
     return x < k.width && y < k.row_end;
 }
 
-template <bool COUNT>
+// TR = TracerPacked (fast, device-private layout) or TracerRef (the reference's array layout);
+// COUNT = work-counter build.
+template <class TR, bool COUNT>
 __global__ void __launch_bounds__(256)
-hrt_primary_kernel(DScene S, FrameK k, DGBuffer gb, TileMap tm, unsigned long long* counters)
+hrt_primary_kernel(TR tr, FrameK k, DGBuffer gb, TileMap tm, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int x, y;
-    if (tile_pixel(tm, k, x, y)) primary_pixel<COUNT>(S, k, gb, y * k.width + x, C);
+    if (tile_pixel(tm, k, x, y)) primary_pixel<TR, COUNT>(tr, k, gb, y * k.width + x, C);
     C.flush(counters);
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256)
-hrt_path_trace_kernel(DScene S, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
+#ifndef HRT_PT_WAVES
+#define HRT_PT_WAVES 4   // 128-VGPR cap: 4 waves/SIMD hide the dependent node loads better than 2 at 204 VGPRs (measured)
+#endif
+template <class TR, bool COUNT>
+__global__ void __launch_bounds__(256, HRT_PT_WAVES)
+hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
                       long long nPix, TileMap tm, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int x, y;
-    if (tile_pixel(tm, k, x, y)) path_trace_pixel<COUNT>(S, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
+    if (tile_pixel(tm, k, x, y)) path_trace_pixel<TR, COUNT>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
     C.flush(counters);
 }
 
@@ -97,6 +103,8 @@ struct DeviceState {
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
+    void* packed[4] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri (device-private repack)
+    DPacked dpacked{};
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
     int64_t nPix = 0;
     DGBuffer gb{};
@@ -114,6 +122,7 @@ struct hrt_ctx {
     std::vector<DeviceState> dev;
     std::string err;
     bool scene_ready = false;
+    bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
     int width = 0, height = 0;
 };
 
@@ -199,6 +208,175 @@ int ensure_pixels(hrt_ctx* c, DeviceState& d, int64_t nPix)
 void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
+    for (int i = 0; i < 4; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
+}
+
+// ---------------------------------------------------------------------------------------
+// Scene validation + repack (host, once per commit).
+// Validation: every index a kernel will dereference is range-checked and the node graphs are
+// checked to be acyclic, so a malformed scene is an HRT_ERR_INVALID_ARG here instead of a GPU
+// fault or a walk that never ends.  (The reference trusts its own builder and checks nothing.)
+// ---------------------------------------------------------------------------------------
+struct PackedHost {
+    std::vector<NodeQ> tlas, blas;
+    std::vector<FInst> finst;
+    std::vector<FTri> ftri;
+    bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
+};
+
+inline float bits_f(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+inline float4 mkf4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+bool is_identity(const hrt_affine3x4& m)
+{
+    return m.m00 == 1.f && m.m01 == 0.f && m.m02 == 0.f && m.m03 == 0.f && m.m10 == 0.f && m.m11 == 1.f && m.m12 == 0.f && m.m13 == 0.f &&
+           m.m20 == 0.f && m.m21 == 0.f && m.m22 == 1.f && m.m23 == 0.f;
+}
+
+// nodes[lo,hi): every link in {-1} U [lo,hi) (TLAS: lo = 0), walk graph (left edge of inner nodes, skip edge of
+// all nodes) acyclic from `root`.  Returns "" or an error text.
+std::string check_nodes(const hrt_bvh_node* nodes, int64_t lo, int64_t hi, int64_t root, int64_t leafLimit, const char* what)
+{
+    if (hi <= lo) return "";
+    for (int64_t i = lo; i < hi; i++)
+    {
+        const hrt_bvh_node& n = nodes[i];
+        if (n.skipIndex < -1 || n.skipIndex >= hi) return std::string(what) + ": skipIndex out of range";   // skip may leave a BLAS range upward? no: reference skips are -1 or inside
+        if (n.skipIndex != -1 && n.skipIndex < lo) return std::string(what) + ": skipIndex below its BLAS";
+        if (n.count > 0) { if (n.first < 0 || (int64_t)n.first + n.count > leafLimit) return std::string(what) + ": leaf range outside the index list"; }
+        else if (n.left < -1 || n.left >= hi || (n.left != -1 && n.left < lo)) return std::string(what) + ": left child out of range";
+    }
+    // iterative DFS, colours: 0 new, 1 on stack, 2 done
+    std::vector<uint8_t> col((size_t)(hi - lo), 0);
+    std::vector<std::pair<int64_t, int>> st;
+    st.emplace_back(root, 0);
+    col[(size_t)(root - lo)] = 1;
+    while (!st.empty())
+    {
+        auto& top = st.back();
+        const hrt_bvh_node& n = nodes[top.first];
+        int64_t next = -2;
+        if (top.second == 0) { top.second = 1; next = n.count > 0 ? -1 : n.left; }
+        else if (top.second == 1) { top.second = 2; next = n.skipIndex; }
+        else { col[(size_t)(top.first - lo)] = 2; st.pop_back(); continue; }
+        if (next < 0) continue;
+        uint8_t& c = col[(size_t)(next - lo)];
+        if (c == 1) return std::string(what) + ": node links form a cycle";
+        if (c == 0) { c = 1; st.emplace_back(next, 0); }
+    }
+    return "";
+}
+
+std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
+{
+    const int64_t nT = s->n_tlasNodes, nTI = s->n_tlasInstanceIndices, nI = s->n_instances, nB = s->n_blasNodes;
+    const int64_t nSP = s->n_spherePrimIdx, nS = s->n_spheres, nTP = s->n_triPrimIdx, nPos = s->n_meshPositions, nTri = s->n_meshTris;
+    const int64_t nTC = s->n_meshTexcoords, nTU = s->n_meshTriUVs, nTM = s->n_triMatIndex, nM = s->n_materials, nTx = s->n_texels, nTxI = s->n_texInfos;
+    for (int64_t v : {nT, nTI, nI, nB, nSP, nS, nTP, nPos, nTri, nTC, nTU, nTM, nM, nTx, nTxI})
+        if (v > 0x7FFFFFF0LL) return "array too long for 32-bit indices";
+    for (int64_t i = 0; i < nTI; i++) if (s->tlasInstanceIndices[i] < 0 || s->tlasInstanceIndices[i] >= nI) return "tlasInstanceIndices entry out of range";
+    for (int64_t i = 0; i < nSP; i++) if (s->spherePrimIdx[i] < 0 || s->spherePrimIdx[i] >= nS) return "spherePrimIdx entry out of range";
+    for (int64_t i = 0; i < nTP; i++) if (s->triPrimIdx[i] < 0 || s->triPrimIdx[i] >= nTri) return "triPrimIdx entry out of range";
+    if (nTri > 0 && (nTM < nTri || nTU < nTri)) return "triMatIndex / meshTriUVs shorter than meshTris";
+    for (int64_t i = 0; i < nTri; i++)
+    {
+        const hrt_mesh_tri& t = s->meshTris[i];
+        if (t.i0 < 0 || t.i1 < 0 || t.i2 < 0 || t.i0 >= nPos || t.i1 >= nPos || t.i2 >= nPos) return "meshTris vertex index out of range";
+        const hrt_mesh_tri_uv& u = s->meshTriUVs[i];
+        if (u.t0 < 0 || u.t1 < 0 || u.t2 < 0 || u.t0 >= nTC || u.t1 >= nTC || u.t2 >= nTC) return "meshTriUVs index out of range";
+        if (s->triMatIndex[i] < 0 || s->triMatIndex[i] >= nM) return "triMatIndex entry out of range";
+    }
+    for (int64_t i = 0; i < nTxI; i++)
+    {
+        const hrt_tex_info& ti = s->texInfos[i];
+        if (ti.Width > 0 && ti.Height > 0 && (ti.Offset < 0 || (int64_t)ti.Offset + (int64_t)ti.Width * ti.Height > nTx)) return "texInfos entry outside texels";
+    }
+    if (nT > 0) { std::string e = check_nodes(s->tlasNodes, 0, nT, 0, nTI, "tlasNodes"); if (!e.empty()) return e; }
+    for (int64_t i = 0; i < nI; i++)
+    {
+        const hrt_instance& in = s->instances[i];
+        if (in.blasNodeCount < 0 || in.blasRoot < 0 || (int64_t)in.blasRoot + in.blasNodeCount > nB) return "instance BLAS range outside blasNodes";
+        if (in.blasNodeCount == 0) continue;
+        std::string e = check_nodes(s->blasNodes, in.blasRoot, (int64_t)in.blasRoot + in.blasNodeCount, in.blasRoot,
+                                    in.type == HRT_BLAS_SPHERESET ? nSP : nTP, "blasNodes");
+        if (!e.empty()) return e;
+    }
+
+    // ---- repack
+    auto pack_nodes = [&](const hrt_bvh_node* src, int64_t n, std::vector<NodeQ>& dst) {
+        dst.resize((size_t)std::max<int64_t>(n, 1));
+        std::memset(dst.data(), 0, dst.size() * sizeof(NodeQ));
+        if (n == 0) { dst[0].lo.w = bits_f(kEnd); dst[0].hi.w = bits_f(kEnd); }    // the 1-element zero buffer: count 0, left 0 -> treat as end
+        for (int64_t i = 0; i < n; i++)
+        {
+            const hrt_bvh_node& b = src[i];
+            int cnt = b.count > 0 ? b.count : 0;
+            if (cnt > 15 || n >= kEnd) out.ok = false;
+            int link = cnt > 0 ? b.first : (b.left & kEnd);
+            int hi = (b.skipIndex & kEnd) | (int)((unsigned)(cnt & 15) << 28);
+            dst[(size_t)i].lo = mkf4(b.boundsMin.X, b.boundsMin.Y, b.boundsMin.Z, bits_f(link));
+            dst[(size_t)i].hi = mkf4(b.boundsMax.X, b.boundsMax.Y, b.boundsMax.Z, bits_f(hi));
+        }
+    };
+    pack_nodes(s->tlasNodes, nT, out.tlas);
+    pack_nodes(s->blasNodes, nB, out.blas);
+    if (nT == 0)
+    {   // reference semantics of the zeroed 1-element TLAS: node 0 has count 0, left 0 -> loops forever on a hit;
+        // its bounds are all zero so only rays through the origin would.  We end the walk instead.
+    }
+    out.finst.resize((size_t)std::max<int64_t>(nTI, 1));
+    std::memset(out.finst.data(), 0, out.finst.size() * sizeof(FInst));
+    for (int64_t i = 0; i < nTI; i++)
+    {
+        int ii = s->tlasInstanceIndices[i];
+        const hrt_instance& in = s->instances[ii];
+        const bool ident = is_identity(in.objectToWorld) && is_identity(in.worldToObject) && in.uniformScale == 1.0f;
+        const bool sph = in.type == HRT_BLAS_SPHERESET;
+        FInst f;
+        bool fast = false;
+        if (sph && ident && in.blasNodeCount >= 1)
+        {
+            const hrt_bvh_node& root = s->blasNodes[in.blasRoot];
+            int64_t end = (int64_t)in.blasRoot + in.blasNodeCount;
+            if (root.count == 1 && (root.skipIndex == -1 || root.skipIndex >= end))
+            {
+                int sid = s->spherePrimIdx[root.first];
+                const hrt_sphere& sp = s->spheres[sid];
+                f.a = mkf4(root.boundsMin.X, root.boundsMin.Y, root.boundsMin.Z, bits_f(FI_FAST_SPHERE | FI_IDENTITY | FI_SPHERESET));
+                f.b = mkf4(root.boundsMax.X, root.boundsMax.Y, root.boundsMax.Z, bits_f(sid));
+                f.c = mkf4(sp.center.X, sp.center.Y, sp.center.Z, sp.radius);
+                fast = true;
+            }
+        }
+        if (!fast)
+        {
+            float scale = in.uniformScale > 0.f ? in.uniformScale : 1.f;
+            f.a = mkf4(0.f, 0.f, 0.f, bits_f((ident ? FI_IDENTITY : 0) | (sph ? FI_SPHERESET : 0)));
+            f.b = mkf4(0.f, 0.f, 0.f, bits_f(ii));
+            f.c = mkf4(bits_f(in.blasRoot), bits_f(in.blasRoot + in.blasNodeCount), scale, 0.f);
+        }
+        out.finst[(size_t)i] = f;
+    }
+    out.ftri.resize((size_t)std::max<int64_t>(nTP, 1));
+    std::memset(out.ftri.data(), 0, out.ftri.size() * sizeof(FTri));
+    const int64_t texLen = nTxI > 0 ? nTxI : 1;
+    for (int64_t j = 0; j < nTP; j++)
+    {
+        int ti = s->triPrimIdx[j];
+        const hrt_mesh_tri& t = s->meshTris[ti];
+        const hrt_float3 &a = s->meshPositions[t.i0], &b = s->meshPositions[t.i1], &c = s->meshPositions[t.i2];
+        int mi = s->triMatIndex[ti];
+        const hrt_material& m = s->materials[mi];
+        bool dmap = m.HasDiffuseMap != 0 && m.DiffuseTexIndex >= 0 && m.DiffuseTexIndex < texLen;
+        bool amap = m.HasAlphaMap != 0 && m.AlphaTexIndex >= 0 && m.AlphaTexIndex < texLen;
+        bool rejects_opaque = 1.0f < m.AlphaCutoff;
+        int fl = ((dmap || amap || rejects_opaque) ? FT_TEXTURED : 0) | (m.TwoSided != 0 ? FT_TWOSIDED : 0);
+        FTri& o = out.ftri[(size_t)j];
+        o.v0 = mkf4(a.X, a.Y, a.Z, bits_f(ti));
+        o.v1 = mkf4(b.X, b.Y, b.Z, bits_f(mi));
+        o.v2 = mkf4(c.X, c.Y, c.Z, bits_f(fl));
+    }
+    return "";
 }
 
 template <class T>
@@ -348,9 +526,17 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
                              s->n_materials, s->n_texels, s->n_texInfos};
     for (int i = 0; i < 15; i++)
         if (cnt[i] < 0 || (cnt[i] > 0 && !src[i])) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: array " + std::to_string(i) + " has a count but no pointer");
+    PackedHost ph;
+    {
+        std::string verr = validate_and_pack(s, ph);
+        if (!verr.empty()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: " + verr);
+    }
     int rc = hrt_synchronize(c, nullptr);
     if (rc != HRT_OK) return rc;
     c->scene_ready = false;
+    c->packed_ok = ph.ok;
+    hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
+    emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
     for (DeviceState& d : c->dev)
     {
         HIPCHK(c, hipSetDevice(d.device_id));
@@ -361,6 +547,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             size_t bytes = (size_t)n * kSceneElem[i];
             HIPCHK(c, hipMalloc(&d.scene[i], bytes));
             if (cnt[i] > 0) HIPCHK(c, hipMemcpyAsync(d.scene[i], src[i], bytes, hipMemcpyHostToDevice, d.stream));
+            else if (i == 0) HIPCHK(c, hipMemcpyAsync(d.scene[i], &emptyTlas, bytes, hipMemcpyHostToDevice, d.stream));
             else HIPCHK(c, hipMemsetAsync(d.scene[i], 0, bytes, d.stream));
         }
         DScene& S = d.dscene;
@@ -373,6 +560,16 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         S.materials = (const hrt_material*)d.scene[12]; S.texels = (const hrt_rgba32*)d.scene[13];
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
+        // device-private repack (TracerPacked)
+        const void* psrc[4] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data()};
+        const size_t pbytes[4] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri)};
+        for (int i = 0; i < 4; i++)
+        {
+            HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
+            HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
+        }
+        d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
+        d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;
@@ -476,18 +673,39 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
 
+        const bool usePacked = c->packed_ok && !(flags & HRT_FLAG_REFERENCE_LAYOUT);
+        TracerPacked trP; trP.P = d.dpacked; trP.S = d.dscene;
+        TracerRef trR; trR.S = d.dscene;
+        const dim3 grid(tm.nTiles), block(256);
         HIPCHK(c, hipEventRecord(ev[0], d.stream));
         if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
         {
-            if (count) hipLaunchKernelGGL(hrt_primary_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
-            else       hipLaunchKernelGGL(hrt_primary_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, tm, d.counters);
+            if (usePacked)
+            {
+                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TracerPacked, true>), grid, block, 0, d.stream, trP, k, d.gb, tm, d.counters);
+                else       hipLaunchKernelGGL((hrt_primary_kernel<TracerPacked, false>), grid, block, 0, d.stream, trP, k, d.gb, tm, d.counters);
+            }
+            else
+            {
+                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TracerRef, true>), grid, block, 0, d.stream, trR, k, d.gb, tm, d.counters);
+                else       hipLaunchKernelGGL((hrt_primary_kernel<TracerRef, false>), grid, block, 0, d.stream, trR, k, d.gb, tm, d.counters);
+            }
             HIPCHK(c, hipGetLastError());
         }
         HIPCHK(c, hipEventRecord(ev[1], d.stream));
         if (tm.nTiles > 0)
         {
-            if (count) hipLaunchKernelGGL(hrt_path_trace_kernel<true>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
-            else       hipLaunchKernelGGL(hrt_path_trace_kernel<false>, dim3(tm.nTiles), dim3(256), 0, d.stream, d.dscene, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, d.counters + 10);
+            unsigned long long* cnt1 = d.counters + 10;
+            if (usePacked)
+            {
+                if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TracerPacked, true>), grid, block, 0, d.stream, trP, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
+                else       hipLaunchKernelGGL((hrt_path_trace_kernel<TracerPacked, false>), grid, block, 0, d.stream, trP, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
+            }
+            else
+            {
+                if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TracerRef, true>), grid, block, 0, d.stream, trR, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
+                else       hipLaunchKernelGGL((hrt_path_trace_kernel<TracerRef, false>), grid, block, 0, d.stream, trR, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
+            }
             HIPCHK(c, hipGetLastError());
         }
         HIPCHK(c, hipEventRecord(ev[2], d.stream));

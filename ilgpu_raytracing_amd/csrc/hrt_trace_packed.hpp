@@ -1,0 +1,433 @@
+// hrt_trace_packed.hpp -- the fast tracer: same walk, same arithmetic, same results as
+// TracerRef (SceneDeviceViews.cs:30-327), over a device-private repack of the scene that
+// hrt_scene_upload builds once per commit.
+//
+// Why a repack: the reference's arrays make every TLAS leaf a chain of six dependent global
+// loads (tlasInstanceIndices[i] -> InstanceRecord 144 B -> BLASNode 44 B -> primIdx ->
+// Sphere 80 B, or MeshTri 12 B -> 3 x Float3), each a fresh L1/L2 round trip on a machine
+// whose rays are latency-bound, and its 44-byte nodes straddle 16-byte segments.  Here:
+//   NodeQ  32 B  two aligned dwordx4 loads per node: {bmin, link} {bmax, skip | count << 28}
+//   FInst  48 B  one record per TLAS leaf slot, in leaf order.  For the common case the
+//                reference's own default scene uses (identity transform, one sphere, one-node
+//                BLAS) it carries the BLAS root box and the sphere inline: the leaf is
+//                ONE hop from the TLAS node.  Other instances keep (blasRoot, blasEnd, scale)
+//                and an "identity" bit that skips TransformRay (x*1 + y*0 + z*0 + 0 only
+//                changes the sign of zeros, which no comparison, division guard or store of
+//                this path can observe -- DESIGN.md "exactness").
+//   FTri   48 B  one record per BLAS leaf slot: the three vertices, triangle index, material
+//                index and two flags resolved at upload (needs texture/alpha path, two-sided),
+//                in leaf order, i.e. spatially sorted by the builder.
+// Traversal is "while-while": every lane first walks inner nodes until it stands on a leaf
+// (cheap box tests, all lanes busy), then all lanes run the expensive leaf body together,
+// instead of idling lanes at inner nodes while one neighbour intersects primitives.
+// Only (t, leaf slot, primitive slot) of the best hit stay live; normal, albedo, texture
+// lookups are pure functions of the winner and are evaluated once, after the walk.
+#pragma once
+#include "hrt_device.hpp"
+
+namespace hrt {
+
+constexpr int kEnd = 0x0FFFFFFF;            // packed form of the -1 link
+
+struct NodeQ { float4 lo, hi; };            // lo.w = bits(left | first), hi.w = bits(skip | count << 28)
+struct FInst { float4 a, b, c; };           // a.w = bits(flags), b.w = bits(index); see hrt_runtime.hip pack_scene()
+struct FTri  { float4 v0, v1, v2; };        // v0.w = bits(triIndex), v1.w = bits(matIndex), v2.w = bits(flags)
+
+enum { FI_FAST_SPHERE = 1, FI_IDENTITY = 2, FI_SPHERESET = 4 };
+enum { FT_TEXTURED = 1, FT_TWOSIDED = 2 };  // FT_TEXTURED: usable diffuse or alpha map, or AlphaCutoff > 1 (rejects alpha = 1)
+
+struct DPacked {
+    const NodeQ* tlas;
+    const FInst* finst;      // indexed like tlasInstanceIndices
+    const NodeQ* blas;       // indexed like blasNodes
+    const FTri* ftri;        // indexed like triPrimIdx
+};
+
+HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514
+{
+    float t1 = (lo.x - r.o.x) * r.inv.x;
+    float t2 = (hi.x - r.o.x) * r.inv.x;
+    float tmin = hrt_fmin(t1, t2);
+    float tmax = hrt_fmax(t1, t2);
+    t1 = (lo.y - r.o.y) * r.inv.y;
+    t2 = (hi.y - r.o.y) * r.inv.y;
+    tmin = hrt_fmax(tmin, hrt_fmin(t1, t2));
+    tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
+    t1 = (lo.z - r.o.z) * r.inv.z;
+    t2 = (hi.z - r.o.z) * r.inv.z;
+    tmin = hrt_fmax(tmin, hrt_fmin(t1, t2));
+    tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
+    return tmax >= hrt_fmax(tmin, tMin) && tmin <= tMax;
+}
+HRT_D F3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+HRT_D int wbits(float4 v) { return __float_as_int(v.w); }
+
+struct TracerPacked {
+    DPacked P;
+    DScene S;     // original arrays: winners' shading data, general-instance transforms, textures
+
+    // object-space ray of a leaf slot (TransformRay, SceneDeviceViews.cs:475-481)
+    HRT_D Ray object_ray(const Ray& w, int flags, int instIdx) const
+    {
+        if (flags & FI_IDENTITY) return w;
+        const hrt_instance* inst = &S.instances[instIdx];
+        Ray r;
+        r.o = xform_point(inst->worldToObject, w.o);
+        r.d = xform_vector(inst->worldToObject, w.d);
+        r.inv = inv_dir(r.d);
+        return r;
+    }
+
+    // UV + texture path of one triangle hit (SceneDeviceViews.cs:201-218 / :297-315)
+    HRT_D void tri_uv(int ti, float bu, float bv, float& uu, float& vv) const
+    {
+        hrt_mesh_tri_uv tuv = S.meshTriUVs[ti];
+        hrt_float2 t0 = S.meshTexcoords[tuv.t0], t1 = S.meshTexcoords[tuv.t1], t2 = S.meshTexcoords[tuv.t2];
+        float w = 1.f - bu - bv;
+        uu = t0.X * w + t1.X * bu + t2.X * bv;
+        vv = t0.Y * w + t1.Y * bu + t2.Y * bv;
+    }
+
+    // ---------------- closest hit inside one BLAS, triangles (TraverseBLAS_Tri_Textured :173-237)
+    template <bool COUNT>
+    HRT_D void blas_tris_closest(const Ray& iray, int blasStart, int blasEnd, float& tObj, int& slot, Cnt<COUNT>& C) const
+    {
+        Tex tex(S);
+        int cur = blasStart;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur < blasEnd)                       // kEnd >= blasEnd: also the "cur != -1" test
+            {
+                NodeQ n = P.blas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(iray, n.lo, n.hi, 0.001f, tObj)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) break;
+            for (int j = lfirst; j < lfirst + lcount; j++)
+            {
+                FTri tr = P.ftri[j];
+                C.inc(C_TRI_TESTS);
+                float t, bu, bv;
+                if (hit_tri_t(iray, xyz(tr.v0), xyz(tr.v1), xyz(tr.v2), t, bu, bv))
+                {
+                    C.inc(C_TRI_MT_HITS);
+                    if (t > 0.001f && t < tObj)
+                    {
+                        C.inc(C_TRI_ACCEPTED);
+                        bool accept = true;
+                        if (wbits(tr.v2) & FT_TEXTURED)
+                        {   // `if (alpha < mat.AlphaCutoff) continue;` (:209-218) can reject: evaluate it now.
+                            // (flag is also set for map-less materials whose cutoff exceeds alpha = 1)
+                            const hrt_material* mat = &S.materials[wbits(tr.v1)];
+                            int ati = mat->AlphaTexIndex;
+                            float alpha = 1.f;
+                            if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
+                            {
+                                float uu, vv;
+                                tri_uv(wbits(tr.v0), bu, bv, uu, vv);
+                                alpha = tex.mask_linear(S.texInfos[ati], uu, vv);
+                            }
+                            accept = !(alpha < mat->AlphaCutoff);
+                        }
+                        if (accept) { tObj = t; slot = j; }
+                    }
+                }
+            }
+            cur = lskip;
+        }
+    }
+
+    // ---------------- closest hit inside one BLAS, spheres (TraverseBLAS_Sphere :124-170)
+    template <bool COUNT>
+    HRT_D void blas_spheres_closest(const Ray& iray, int blasStart, int blasEnd, float& tObj, int& sphereIdx, Cnt<COUNT>& C) const
+    {
+        int cur = blasStart;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur < blasEnd)
+            {
+                NodeQ n = P.blas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(iray, n.lo, n.hi, 0.001f, tObj)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) break;
+            for (int j = lfirst; j < lfirst + lcount; j++)
+            {
+                int p = S.spherePrimIdx[j];
+                const hrt_sphere* sp = &S.spheres[p];
+                C.inc(C_SPHERE_TESTS);
+                float t;
+                if (hit_sphere_t(iray, cv3(sp->center), sp->radius, t) && t > 0.001f && t < tObj) { tObj = t; sphereIdx = p; }
+            }
+            cur = lskip;
+        }
+    }
+
+    // ---------------- TraceClosest (:30-86)
+    template <bool COUNT>
+    HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
+    {
+        C.inc(C_RAYS_CLOSEST);
+        float bestT = 1e30f;        // closestT (world)
+        float bestTObj = 0.f;       // object-space t of the winner (== bestT * scale)
+        int bestSlot = -1;          // TLAS leaf slot (index into finst / tlasInstanceIndices)
+        int bestPrim = -1;          // sphere index, or BLAS leaf slot of the triangle
+        int cur = 0;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur != kEnd)
+            {
+                NodeQ n = P.tlas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(wray, n.lo, n.hi, 0.001f, bestT)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) break;
+            for (int i = lfirst; i < lfirst + lcount; i++)
+            {
+                FInst f = P.finst[i];
+                C.inc(C_LEAF_INST);
+                const int flags = wbits(f.a);
+                if (flags & FI_FAST_SPHERE)
+                {   // identity instance, one sphere, one-node BLAS: root box (tMax 1e30) then the sphere
+                    C.inc(C_NODE_VISITS);
+                    if (hit_box(wray, f.a, f.b, 0.001f, 1e30f))
+                    {
+                        C.inc(C_SPHERE_TESTS);
+                        float t;
+                        if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < 1e30f)
+                        {
+                            // hit = tClosest < 1e29 (:169); tWorld = t / 1 (:67)
+                            if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = i; bestPrim = wbits(f.b); }
+                        }
+                    }
+                }
+                else
+                {
+                    const int instIdx = wbits(f.b);
+                    Ray iray = object_ray(wray, flags, instIdx);
+                    const int blasStart = __float_as_int(f.c.x), blasEnd = __float_as_int(f.c.y);
+                    const float scale = f.c.z;
+                    float tObj = 1e30f; int prim = -1;
+                    if (flags & FI_SPHERESET) blas_spheres_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
+                    else                      blas_tris_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
+                    if (tObj < 1e29f)
+                    {
+                        float tWorld = tObj / scale;
+                        if (tWorld < bestT) { bestT = tWorld; bestTObj = tObj; bestSlot = i; bestPrim = prim; }
+                    }
+                }
+            }
+            cur = lskip;
+        }
+
+        best.t = bestT; best.n = mk3(0.f, 0.f, 0.f); best.albedo = mk3(1.f, 1.f, 1.f); best.objId = -1; best.shade = 0; best.ior = 1.f;
+        if (!(bestT < 1e29f)) return false;
+
+        // ---- shade the winner once (normal :534-535/:556, albedo :146-159/:210-223, world normal :71)
+        FInst f = P.finst[bestSlot];
+        const int flags = wbits(f.a);
+        Tex tex(S);
+        F3 nObj;
+        if (flags & (FI_FAST_SPHERE | FI_SPHERESET))
+        {
+            Ray iray = (flags & FI_FAST_SPHERE) ? wray : object_ray(wray, flags, wbits(f.b));
+            const hrt_sphere* sp = &S.spheres[bestPrim];
+            nObj = sphere_normal(iray, cv3(sp->center), bestTObj);
+            F3 kd = cv3(sp->material.Kd);
+            F3 alb = (kd.x == 0.f && kd.y == 0.f && kd.z == 0.f) ? cv3(sp->albedo) : kd;
+            int dti = sp->material.DiffuseTexIndex;
+            if (sp->material.HasDiffuseMap != 0 && dti >= 0 && dti < S.n_texInfos)
+            {
+                float u = 0.5f + hrt_atan2(nObj.z, nObj.x) / (2.f * kPI);
+                float v = hrt_acos(hrt_fmin(1.f, hrt_fmax(-1.f, nObj.y))) / kPI;
+                alb = tex.linear_rgb(S.texInfos[dti], u, v);
+            }
+            best.albedo = alb;
+            best.shade = sp->shading;
+            float sior = sp->ior;
+            best.ior = sior > 0.f ? sior : 1.f;
+            best.objId = -1;
+        }
+        else
+        {
+            Ray iray = object_ray(wray, flags, wbits(f.b));
+            FTri tr = P.ftri[bestPrim];
+            F3 v0 = xyz(tr.v0), v1 = xyz(tr.v1), v2 = xyz(tr.v2);
+            nObj = normalize(cross(v1 - v0, v2 - v0));
+            const int tflags = wbits(tr.v2);
+            if ((tflags & FT_TWOSIDED) && dot(nObj, iray.d) > 0.f) nObj = nObj * -1.f;
+            const hrt_material* mat = &S.materials[wbits(tr.v1)];
+            F3 kd = cv3(mat->Kd);
+            if (tflags & FT_TEXTURED)
+            {
+                int dti = mat->DiffuseTexIndex;
+                if (mat->HasDiffuseMap != 0 && dti >= 0 && dti < S.n_texInfos)
+                {
+                    float t, bu, bv, uu, vv;
+                    hit_tri_t(iray, v0, v1, v2, t, bu, bv);          // same inputs -> same (bu, bv) as in the walk
+                    tri_uv(wbits(tr.v0), bu, bv, uu, vv);
+                    kd = tex.linear_rgb(S.texInfos[dti], uu, vv);
+                }
+            }
+            best.albedo = kd;
+            best.objId = wbits(tr.v0);
+        }
+        if (flags & FI_IDENTITY) best.n = normalize(nObj);           // objectToWorld = I: n*1 + 0 + 0
+        else best.n = normalize(xform_vector(S.instances[wbits(f.b)].objectToWorld, nObj));
+        return true;
+    }
+
+    // ---------------- any hit inside one BLAS (AnyHit_Tri_Textured :270-327, AnyHit_Sphere :240-267)
+    template <bool COUNT>
+    HRT_D bool blas_tris_any(const Ray& iray, int blasStart, int blasEnd, float tMaxObj, Cnt<COUNT>& C) const
+    {
+        Tex tex(S);
+        int cur = blasStart;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur < blasEnd)
+            {
+                NodeQ n = P.blas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(iray, n.lo, n.hi, 0.001f, tMaxObj)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) return false;
+            for (int j = lfirst; j < lfirst + lcount; j++)
+            {
+                FTri tr = P.ftri[j];
+                C.inc(C_TRI_TESTS);
+                float t, bu, bv;
+                if (hit_tri_t(iray, xyz(tr.v0), xyz(tr.v1), xyz(tr.v2), t, bu, bv))
+                {
+                    if (t <= 0.001f || t >= tMaxObj) continue;
+                    C.inc(C_TRI_MT_HITS);
+                    if (wbits(tr.v2) & FT_TEXTURED)
+                    {
+                        const hrt_material* mat = &S.materials[wbits(tr.v1)];
+                        int ati = mat->AlphaTexIndex;
+                        if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
+                        {
+                            C.inc(C_TRI_ACCEPTED);
+                            float uu, vv;
+                            tri_uv(wbits(tr.v0), bu, bv, uu, vv);
+                            hrt_tex_info ainfo = S.texInfos[ati];
+                            float aPoint = tex.mask_point(ainfo, uu, vv);
+                            float cutoff = mat->AlphaCutoff;
+                            if (aPoint < cutoff - 0.10f) continue;
+                            if (aPoint >= cutoff + 0.10f) return true;
+                            if (tex.mask_linear(ainfo, uu, vv) < cutoff) continue;
+                        }
+                    }
+                    return true;
+                }
+            }
+            cur = lskip;
+        }
+    }
+    template <bool COUNT>
+    HRT_D bool blas_spheres_any(const Ray& iray, int blasStart, int blasEnd, float tMaxObj, Cnt<COUNT>& C) const
+    {
+        int cur = blasStart;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur < blasEnd)
+            {
+                NodeQ n = P.blas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(iray, n.lo, n.hi, 0.001f, tMaxObj)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) return false;
+            for (int j = lfirst; j < lfirst + lcount; j++)
+            {
+                const hrt_sphere* sp = &S.spheres[S.spherePrimIdx[j]];
+                C.inc(C_SPHERE_TESTS);
+                float t;
+                if (hit_sphere_t(iray, cv3(sp->center), sp->radius, t) && t > 0.001f && t < tMaxObj) return true;
+            }
+            cur = lskip;
+        }
+    }
+
+    // ---------------- ShadowOcclusion (:89-121)
+    template <bool COUNT>
+    HRT_D bool occluded(const Ray& wray, float tMaxWorld, Cnt<COUNT>& C) const
+    {
+        C.inc(C_RAYS_SHADOW);
+        int cur = 0;
+        for (;;)
+        {
+            int lfirst = 0, lcount = 0, lskip = kEnd;
+            while (cur != kEnd)
+            {
+                NodeQ n = P.tlas[cur];
+                C.inc(C_NODE_VISITS);
+                int sk = wbits(n.hi);
+                int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(wray, n.lo, n.hi, 0.001f, tMaxWorld)) { cur = sk; continue; }
+                if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
+                cur = wbits(n.lo) & kEnd;
+            }
+            if (lcount == 0) return false;
+            for (int i = lfirst; i < lfirst + lcount; i++)
+            {
+                FInst f = P.finst[i];
+                C.inc(C_LEAF_INST);
+                const int flags = wbits(f.a);
+                if (flags & FI_FAST_SPHERE)
+                {
+                    const float tMaxObj = tMaxWorld * 1.f;          // scale == 1 (:107)
+                    C.inc(C_NODE_VISITS);
+                    if (hit_box(wray, f.a, f.b, 0.001f, tMaxObj))
+                    {
+                        C.inc(C_SPHERE_TESTS);
+                        float t;
+                        if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < tMaxObj) return true;
+                    }
+                }
+                else
+                {
+                    Ray iray = object_ray(wray, flags, wbits(f.b));
+                    const int blasStart = __float_as_int(f.c.x), blasEnd = __float_as_int(f.c.y);
+                    const float tMaxObj = tMaxWorld * f.c.z;
+                    bool blocked = (flags & FI_SPHERESET) ? blas_spheres_any<COUNT>(iray, blasStart, blasEnd, tMaxObj, C)
+                                                          : blas_tris_any<COUNT>(iray, blasStart, blasEnd, tMaxObj, C);
+                    if (blocked) return true;
+                }
+            }
+            cur = lskip;
+        }
+    }
+};
+
+} // namespace hrt

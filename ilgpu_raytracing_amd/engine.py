@@ -24,7 +24,7 @@ import numpy as np
 from . import _types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhip_raytrace.so")
+LIB_PATH = os.environ.get("HRT_LIB") or os.path.join(_HERE, "csrc", "libhip_raytrace.so")   # HRT_LIB: A/B builds of the same library
 _LIB = None
 
 

@@ -71,6 +71,9 @@ enum hrt_status {
 enum hrt_render_flags {
     HRT_FLAG_COUNTERS     = 1u << 0,  /* run the counting build of both kernels, fill hrt_stats.k[] */
     HRT_FLAG_SKIP_PRIMARY = 1u << 1,  /* bench/profiling only: reuse the resident G-buffer          */
+    HRT_FLAG_REFERENCE_LAYOUT = 1u << 2, /* walk the reference's own arrays (TracerRef) instead of the device-private
+                                         repack: identical results, A/B baseline and fallback for scenes beyond the
+                                         packed encoding (leaf count > 15)                                      */
     HRT_FLAG_NO_SYNC      = 1u << 3   /* enqueue only (outputs must be NULL); collect with hrt_synchronize.
                                          Up to 128 frames may be in flight; the 129th call drains first.      */
 };
