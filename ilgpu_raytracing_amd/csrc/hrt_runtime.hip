@@ -14,6 +14,7 @@
 #include <vector>
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
+#include "hrt_wavefront.hpp"
 #include "../../include/hip_raytrace.h"
 
 using namespace hrt;
@@ -67,6 +68,69 @@ hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir 
     C.flush(counters);
 }
 
+// ---------------------------------------------------------------------------------------
+// Streamed path-trace stage (hrt_wavefront.hpp): one wave per range of kRange path slots.
+// Ranges are handed to workgroups through the same per-XCD contiguous remap as pixel tiles,
+// so neighbouring ranges (neighbouring screen regions) share an L2.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int wf_range(int nRanges)
+{
+    int nBlocks = gridDim.x, orig = blockIdx.x;
+    int q = nBlocks >> 3, r = nBlocks & 7;
+    int xcd = orig & 7, seq = orig >> 3;
+    int blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+    int range = blk * 4 + (threadIdx.x >> 6);
+    return range < nRanges ? range : -1;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_wf_init_kernel(FrameK k, WfGeom g, DGBuffer gb, WfBuffers W)
+{
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_init_wave<COUNT>(k, g, gb, W, range);
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_wf_shade_kernel(FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long long nPix, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_shade_wave<COUNT>(k, g, gb, resPrev, nPix, W, vsel ? W.B : W.A, depth, range, C);
+    C.flush(counters);
+}
+
+#ifndef HRT_WF_TRACE_WAVES
+#define HRT_WF_TRACE_WAVES 8
+#endif
+template <class TR, bool COUNT>
+__global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
+hrt_wf_shadow_kernel(TR tr, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_shadow_wave<TR, COUNT>(tr, W, vsel ? W.B : W.A, depth, range, C);
+    C.flush(counters);
+}
+
+template <class TR, bool COUNT>
+__global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
+hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_closest_wave<TR, COUNT>(tr, k, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range, C);
+    C.flush(counters);
+}
+
+__global__ void __launch_bounds__(256)
+hrt_wf_resolve_kernel(FrameK k, WfGeom g, DGBuffer gb, DFramebuffer fb, DReservoir resCur, WfBuffers W)
+{
+    int ord = blockIdx.x * 256 + threadIdx.x;
+    if (ord < g.nOrd) wf_resolve_pixel(k, g, gb, fb, resCur, W, ord);
+}
+
 // exactness probe: evaluates include/hrt_math.h on the device (tests compare with the oracle's bits)
 __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float* y, float* out)
 {
@@ -105,6 +169,9 @@ struct DeviceState {
     DScene dscene{};
     void* packed[4] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri (device-private repack)
     DPacked dpacked{};
+    // streamed path-trace workspace
+    float* wf_mem = nullptr; size_t wf_bytes = 0;
+    int* wf_cnt = nullptr; size_t wf_cnt_ints = 0;
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
     int64_t nPix = 0;
     DGBuffer gb{};
@@ -123,6 +190,7 @@ struct hrt_ctx {
     std::string err;
     bool scene_ready = false;
     bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
+    int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
     int width = 0, height = 0;
 };
 
@@ -205,6 +273,13 @@ int ensure_pixels(hrt_ctx* c, DeviceState& d, int64_t nPix)
     return HRT_OK;
 }
 
+void free_workspace(DeviceState& d)
+{
+    if (d.wf_mem) (void)hipFree(d.wf_mem);
+    if (d.wf_cnt) (void)hipFree(d.wf_cnt);
+    d.wf_mem = nullptr; d.wf_cnt = nullptr; d.wf_bytes = 0; d.wf_cnt_ints = 0;
+}
+
 void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
@@ -222,6 +297,7 @@ struct PackedHost {
     std::vector<FInst> finst;
     std::vector<FTri> ftri;
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
+    int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
 };
 
 inline float bits_f(int v) { float f; std::memcpy(&f, &v, 4); return f; }
@@ -350,6 +426,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         }
         if (!fast)
         {
+            out.feat |= 1;
             float scale = in.uniformScale > 0.f ? in.uniformScale : 1.f;
             f.a = mkf4(0.f, 0.f, 0.f, bits_f((ident ? FI_IDENTITY : 0) | (sph ? FI_SPHERESET : 0)));
             f.b = mkf4(0.f, 0.f, 0.f, bits_f(ii));
@@ -371,6 +448,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         bool amap = m.HasAlphaMap != 0 && m.AlphaTexIndex >= 0 && m.AlphaTexIndex < texLen;
         bool rejects_opaque = 1.0f < m.AlphaCutoff;
         int fl = ((dmap || amap || rejects_opaque) ? FT_TEXTURED : 0) | (m.TwoSided != 0 ? FT_TWOSIDED : 0);
+        if (amap || rejects_opaque) out.feat |= 2;          // the walk itself must evaluate alpha (diffuse-only maps are resolved after it)
         FTri& o = out.ftri[(size_t)j];
         o.v0 = mkf4(a.X, a.Y, a.Z, bits_f(ti));
         o.v1 = mkf4(b.X, b.Y, b.Z, bits_f(mi));
@@ -403,6 +481,97 @@ int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
     {
         size_t off = ((size_t)d.row_begin + (size_t)lastStrip * 8) * rowElems;
         HIPCHK(c, hipMemcpyAsync(host + off, devp + off, (size_t)lastRows * rowElems * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+    }
+    return HRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The path-trace launch of one device, either as the one-pixel-per-lane megakernel or as the
+// streamed pipeline of hrt_wavefront.hpp (default).
+// ---------------------------------------------------------------------------------------
+constexpr long long kWfMaxPaths = 1ll << 25;      // paths resident per sample batch (320 B of workspace each)
+
+int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nRanges, int maxDepth, WfBuffers& W)
+{
+    const size_t planes = 2 * V_PLANES + R_PLANES + S_PLANES + 3 + G_PLANES;
+    const size_t bytes = ((size_t)planes * (size_t)cap + 3 * (size_t)nOrd) * sizeof(float);
+    const size_t ints = (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
+    if (bytes > d.wf_bytes)
+    {
+        if (d.wf_mem) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.wf_mem); d.wf_mem = nullptr; d.wf_bytes = 0; }
+        void* v = nullptr;
+        HIPCHK(c, hipMalloc(&v, bytes));
+        d.wf_mem = (float*)v; d.wf_bytes = bytes;
+    }
+    if (ints > d.wf_cnt_ints)
+    {
+        if (d.wf_cnt) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.wf_cnt); d.wf_cnt = nullptr; d.wf_cnt_ints = 0; }
+        void* v = nullptr;
+        HIPCHK(c, hipMalloc(&v, ints * sizeof(int)));
+        d.wf_cnt = (int*)v; d.wf_cnt_ints = ints;
+    }
+    float* m = d.wf_mem;
+    auto take = [&](int nplanes, long long stride) { Planes pl; pl.base = m; pl.stride = stride; m += (size_t)nplanes * (size_t)stride; return pl; };
+    W.A = take(V_PLANES, cap); W.B = take(V_PLANES, cap); W.R = take(R_PLANES, cap); W.SQ = take(S_PLANES, cap);
+    W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap); W.accum = take(3, nOrd);
+    W.cntA = d.wf_cnt; W.cntS = d.wf_cnt + (size_t)(maxDepth + 1) * (size_t)nRanges;
+    W.nRanges = nRanges;
+    return HRT_OK;
+}
+
+template <class TR>
+int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, const TileMap& tm, int width,
+                   const DReservoir& resPrev, const DReservoir& resCur, long long nPix, bool count, bool mega)
+{
+    unsigned long long* cnt1 = d.counters + 10;
+    if (tm.nTiles <= 0) return HRT_OK;
+    if (mega || k.maxDepth > 64)
+    {
+        const dim3 grid(tm.nTiles), block(256);
+        if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
+        else       hipLaunchKernelGGL((hrt_path_trace_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
+        HIPCHK(c, hipGetLastError());
+        return HRT_OK;
+    }
+    WfGeom g;
+    g.tilesX8 = (width + 7) / 8;
+    g.nOrd = g.tilesX8 * d.n_strips * 64;
+    const int spp = k.spp > 1 ? k.spp : 1;
+    long long sb = kWfMaxPaths / g.nOrd;
+    if (sb < 1) sb = 1;
+    if (sb > spp) sb = spp;
+    const long long batchPaths = sb * (long long)g.nOrd;
+    const int nRanges = (int)((batchPaths + kRange - 1) / kRange);
+    const long long cap = (long long)nRanges * kRange;
+    WfBuffers W;
+    int rc = ensure_workspace(c, d, cap, g.nOrd, nRanges, k.maxDepth, W);
+    if (rc != HRT_OK) return rc;
+    const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
+    for (int b0 = 0; b0 < spp; b0 += (int)sb)
+    {
+        g.batchStart = b0;
+        g.batchCount = (int)std::min<long long>(sb, spp - b0);
+        g.lastBatch = (b0 + g.batchCount >= spp) ? 1 : 0;
+        if (count) hipLaunchKernelGGL((hrt_wf_init_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, W);
+        else       hipLaunchKernelGGL((hrt_wf_init_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, W);
+        for (int depth = 0; depth < k.maxDepth; depth++)
+        {
+            const int vsel = depth & 1;
+            if (count)
+            {
+                hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+            }
+            else
+            {
+                hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+            }
+        }
+        hipLaunchKernelGGL(hrt_wf_resolve_kernel, gridP, block, 0, d.stream, k, g, d.gb, d.fb, resCur, W);
+        HIPCHK(c, hipGetLastError());
     }
     return HRT_OK;
 }
@@ -467,6 +636,7 @@ void hrt_destroy(hrt_ctx* c)
         if (d.stream) (void)hipStreamSynchronize(d.stream);
         free_pixels(d);
         free_scene(d);
+        free_workspace(d);
         if (d.counters) (void)hipFree(d.counters);
         for (int f = 0; f < DeviceState::kRing; f++)
             for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
@@ -535,6 +705,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     if (rc != HRT_OK) return rc;
     c->scene_ready = false;
     c->packed_ok = ph.ok;
+    c->packed_feat = (ph.feat & 2) ? 3 : (ph.feat & 1);
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
     for (DeviceState& d : c->dev)
@@ -673,41 +844,30 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
 
+        // tracer variant: the smallest packed walker that covers the committed scene, or the reference layout
         const bool usePacked = c->packed_ok && !(flags & HRT_FLAG_REFERENCE_LAYOUT);
-        TracerPacked trP; trP.P = d.dpacked; trP.S = d.dscene;
-        TracerRef trR; trR.S = d.dscene;
+        const int variant = usePacked ? c->packed_feat : -1;
+        const bool mega = (flags & HRT_FLAG_MEGAKERNEL) != 0;
+        const bool doPrimary = tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY);
         const dim3 grid(tm.nTiles), block(256);
-        HIPCHK(c, hipEventRecord(ev[0], d.stream));
-        if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
-        {
-            if (usePacked)
+        auto run = [&](auto tr) -> int {
+            using TR = decltype(tr);
+            HIPCHK(c, hipEventRecord(ev[0], d.stream));
+            if (doPrimary)
             {
-                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TracerPacked, true>), grid, block, 0, d.stream, trP, k, d.gb, tm, d.counters);
-                else       hipLaunchKernelGGL((hrt_primary_kernel<TracerPacked, false>), grid, block, 0, d.stream, trP, k, d.gb, tm, d.counters);
+                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
+                else       hipLaunchKernelGGL((hrt_primary_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
+                HIPCHK(c, hipGetLastError());
             }
-            else
-            {
-                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TracerRef, true>), grid, block, 0, d.stream, trR, k, d.gb, tm, d.counters);
-                else       hipLaunchKernelGGL((hrt_primary_kernel<TracerRef, false>), grid, block, 0, d.stream, trR, k, d.gb, tm, d.counters);
-            }
-            HIPCHK(c, hipGetLastError());
-        }
-        HIPCHK(c, hipEventRecord(ev[1], d.stream));
-        if (tm.nTiles > 0)
-        {
-            unsigned long long* cnt1 = d.counters + 10;
-            if (usePacked)
-            {
-                if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TracerPacked, true>), grid, block, 0, d.stream, trP, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
-                else       hipLaunchKernelGGL((hrt_path_trace_kernel<TracerPacked, false>), grid, block, 0, d.stream, trP, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
-            }
-            else
-            {
-                if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TracerRef, true>), grid, block, 0, d.stream, trR, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
-                else       hipLaunchKernelGGL((hrt_path_trace_kernel<TracerRef, false>), grid, block, 0, d.stream, trR, k, d.gb, d.fb, resPrev, resCur, (long long)nPix, tm, cnt1);
-            }
-            HIPCHK(c, hipGetLastError());
-        }
+            HIPCHK(c, hipEventRecord(ev[1], d.stream));
+            return run_path_stage(c, d, tr, k, tm, p->width, resPrev, resCur, (long long)nPix, count, mega);
+        };
+        int rcs;
+        if (variant == 0)      { TracerPackedT<0> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
+        else if (variant == 1) { TracerPackedT<1> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
+        else if (variant == 3) { TracerPackedT<3> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
+        else                   { TracerRef t; t.S = d.dscene; rcs = run(t); }
+        if (rcs != HRT_OK) return rcs;
         HIPCHK(c, hipEventRecord(ev[2], d.stream));
 
         if (out)

@@ -59,10 +59,38 @@ HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)  
     tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
     return tmax >= hrt_fmax(tmin, tMin) && tmin <= tMax;
 }
+// The world ray is dead weight while a general instance's BLAS is walked with the object-space
+// ray, but it must survive for the rest of the TLAS walk.  hipcc can only spill to scratch
+// (global memory, hundreds of cycles inside a latency-bound loop); parking the 9 floats in LDS
+// instead costs one ds_write/ds_read pair per general leaf and keeps the walk at 64 VGPRs.
+// Layout [component][thread]: conflict-free, 9 KiB per 256-thread workgroup.
+struct RayPark {
+    float (*sh)[256];
+    HRT_D void put(const Ray& r) const
+    {
+        const int t = threadIdx.x;
+        sh[0][t] = r.o.x; sh[1][t] = r.o.y; sh[2][t] = r.o.z; sh[3][t] = r.d.x; sh[4][t] = r.d.y; sh[5][t] = r.d.z;
+        sh[6][t] = r.inv.x; sh[7][t] = r.inv.y; sh[8][t] = r.inv.z;
+    }
+    HRT_D Ray get() const
+    {
+        const int t = threadIdx.x;
+        Ray r;
+        r.o = mk3(sh[0][t], sh[1][t], sh[2][t]); r.d = mk3(sh[3][t], sh[4][t], sh[5][t]); r.inv = mk3(sh[6][t], sh[7][t], sh[8][t]);
+        return r;
+    }
+};
 HRT_D F3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 HRT_D int wbits(float4 v) { return __float_as_int(v.w); }
 
-struct TracerPacked {
+// FEAT bit 0: the scene has leaf slots that are not fast spheres (general walkers compiled in)
+// FEAT bit 1: some triangle needs the in-walk alpha / texture path (FT_TEXTURED)
+// hrt_scene_upload picks the smallest variant that covers the committed scene: code that cannot
+// run is not compiled in, which keeps the sphere-only walk within 64 VGPRs (8 waves/SIMD).
+template <int FEAT>
+struct TracerPackedT {
+    static constexpr bool kGeneral = (FEAT & 1) != 0;
+    static constexpr bool kAlpha = (FEAT & 2) != 0;
     DPacked P;
     DScene S;     // original arrays: winners' shading data, general-instance transforms, textures
 
@@ -121,7 +149,7 @@ struct TracerPacked {
                     {
                         C.inc(C_TRI_ACCEPTED);
                         bool accept = true;
-                        if (wbits(tr.v2) & FT_TEXTURED)
+                        if (kAlpha && (wbits(tr.v2) & FT_TEXTURED))
                         {   // `if (alpha < mat.AlphaCutoff) continue;` (:209-218) can reject: evaluate it now.
                             // (flag is also set for map-less materials whose cutoff exceeds alpha = 1)
                             const hrt_material* mat = &S.materials[wbits(tr.v1)];
@@ -177,8 +205,11 @@ struct TracerPacked {
 
     // ---------------- TraceClosest (:30-86)
     template <bool COUNT>
-    HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
+    HRT_D bool closest(const Ray& wray_in, Hit& best, Cnt<COUNT>& C) const
     {
+        __shared__ float park_mem[kGeneral ? 9 : 1][256];
+        RayPark park; park.sh = park_mem;
+        Ray wray = wray_in;
         C.inc(C_RAYS_CLOSEST);
         float bestT = 1e30f;        // closestT (world)
         float bestTObj = 0.f;       // object-space t of the winner (== bestT * scale)
@@ -219,15 +250,19 @@ struct TracerPacked {
                         }
                     }
                 }
-                else
+                else if (kGeneral)
                 {
                     const int instIdx = wbits(f.b);
-                    Ray iray = object_ray(wray, flags, instIdx);
                     const int blasStart = __float_as_int(f.c.x), blasEnd = __float_as_int(f.c.y);
                     const float scale = f.c.z;
                     float tObj = 1e30f; int prim = -1;
-                    if (flags & FI_SPHERESET) blas_spheres_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
-                    else                      blas_tris_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
+                    {
+                        park.put(wray);                              // world ray rests in LDS during the BLAS walk
+                        Ray iray = object_ray(wray, flags, instIdx);
+                        if (flags & FI_SPHERESET) blas_spheres_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
+                        else                      blas_tris_closest<COUNT>(iray, blasStart, blasEnd, tObj, prim, C);
+                        wray = park.get();
+                    }
                     if (tObj < 1e29f)
                     {
                         float tWorld = tObj / scale;
@@ -246,9 +281,9 @@ struct TracerPacked {
         const int flags = wbits(f.a);
         Tex tex(S);
         F3 nObj;
-        if (flags & (FI_FAST_SPHERE | FI_SPHERESET))
+        if (!kGeneral || (flags & (FI_FAST_SPHERE | FI_SPHERESET)))
         {
-            Ray iray = (flags & FI_FAST_SPHERE) ? wray : object_ray(wray, flags, wbits(f.b));
+            Ray iray = (!kGeneral || (flags & FI_FAST_SPHERE)) ? wray : object_ray(wray, flags, wbits(f.b));
             const hrt_sphere* sp = &S.spheres[bestPrim];
             nObj = sphere_normal(iray, cv3(sp->center), bestTObj);
             F3 kd = cv3(sp->material.Kd);
@@ -290,7 +325,7 @@ struct TracerPacked {
             best.albedo = kd;
             best.objId = wbits(tr.v0);
         }
-        if (flags & FI_IDENTITY) best.n = normalize(nObj);           // objectToWorld = I: n*1 + 0 + 0
+        if (!kGeneral || (flags & FI_IDENTITY)) best.n = normalize(nObj);   // objectToWorld = I: n*1 + 0 + 0
         else best.n = normalize(xform_vector(S.instances[wbits(f.b)].objectToWorld, nObj));
         return true;
     }
@@ -325,7 +360,7 @@ struct TracerPacked {
                 {
                     if (t <= 0.001f || t >= tMaxObj) continue;
                     C.inc(C_TRI_MT_HITS);
-                    if (wbits(tr.v2) & FT_TEXTURED)
+                    if (kAlpha && (wbits(tr.v2) & FT_TEXTURED))
                     {
                         const hrt_material* mat = &S.materials[wbits(tr.v1)];
                         int ati = mat->AlphaTexIndex;
@@ -380,8 +415,11 @@ struct TracerPacked {
 
     // ---------------- ShadowOcclusion (:89-121)
     template <bool COUNT>
-    HRT_D bool occluded(const Ray& wray, float tMaxWorld, Cnt<COUNT>& C) const
+    HRT_D bool occluded(const Ray& wray_in, float tMaxWorld, Cnt<COUNT>& C) const
     {
+        __shared__ float park_mem[kGeneral ? 9 : 1][256];
+        RayPark park; park.sh = park_mem;
+        Ray wray = wray_in;
         C.inc(C_RAYS_SHADOW);
         int cur = 0;
         for (;;)
@@ -415,19 +453,22 @@ struct TracerPacked {
                         if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < tMaxObj) return true;
                     }
                 }
-                else
+                else if (kGeneral)
                 {
-                    Ray iray = object_ray(wray, flags, wbits(f.b));
                     const int blasStart = __float_as_int(f.c.x), blasEnd = __float_as_int(f.c.y);
                     const float tMaxObj = tMaxWorld * f.c.z;
+                    park.put(wray);
+                    Ray iray = object_ray(wray, flags, wbits(f.b));
                     bool blocked = (flags & FI_SPHERESET) ? blas_spheres_any<COUNT>(iray, blasStart, blasEnd, tMaxObj, C)
                                                           : blas_tris_any<COUNT>(iray, blasStart, blasEnd, tMaxObj, C);
                     if (blocked) return true;
+                    wray = park.get();
                 }
             }
             cur = lskip;
         }
     }
 };
+using TracerPacked = TracerPackedT<3>;       // everything compiled in
 
 } // namespace hrt

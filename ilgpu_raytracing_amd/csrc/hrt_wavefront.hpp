@@ -1,0 +1,388 @@
+// hrt_wavefront.hpp -- the path-trace launch (PathTraceKernel, Engine/RTRay.cs:203-325) as a
+// STREAMED pipeline instead of one megakernel.
+//
+// The reference runs spp x maxDepth bounces of one pixel inside one thread.  On a 64-lane
+// machine that couples three things that want different shapes: BVH walks (latency-bound
+// pointer chasing: wants 8 waves/SIMD and ~40 registers), ReSTIR candidate generation (pure
+// ALU: ~1.5k instructions per vertex, ~100 registers) and path bookkeeping.  Fused, the walk
+// runs at the occupancy of the fattest stage and every lane whose path ended idles until the
+// slowest path of its wave finishes all samples.
+//
+// Here every (pixel, sample) pair is an independent PATH whose state lives in HBM as
+// structure-of-arrays planes (one float per plane per path, so a wave reads/writes 256
+// contiguous bytes per plane), and one bounce is three small kernels:
+//
+//     wf_shade   (ALU)     vertex -> bounce ray (+ shadow-ray request for diffuse vertices)
+//     wf_shadow  (walk)    any-hit; unoccluded -> Li += T * direct
+//     wf_closest (walk)    closest hit -> next vertex, or Li += T * sky and the path ends
+//
+// between wf_init (paths from the G-buffer) and wf_resolve (ordered per-pixel sum over samples,
+// reservoir hand-off, framebuffer store).  Samples of a pixel run concurrently; the only
+// cross-sample orderings of the reference are reproduced explicitly: Lframe is summed in sample
+// order by wf_resolve, and resCur receives the reservoir of the LAST sample that reached a
+// diffuse vertex (RTRay.cs:231,292-296) via a per-path staging plane.
+//
+// Compaction without atomics: the path-id space is cut into RANGES of kRange slots, one wave
+// per range.  A wave compacts its survivors with ballot/popcount prefixes into the front of
+// its own range and records the count; the next kernel's wave of the same range reads only
+// that many.  No global counter, no atomics, deterministic order, every plane access a
+// contiguous 256-byte run per wave.  Dead paths cost nothing; a range whose paths all ended
+// exits on its first scalar load.
+//
+// Arithmetic per path is exactly path_trace_pixel's (hrt_device.hpp): same functions, same
+// order, RNG state carried in a plane, so results stay bit-identical to the oracle.
+#pragma once
+#include "hrt_device.hpp"
+
+namespace hrt {
+
+constexpr int kRange = 256;                  // slots per range (one wave owns one range)
+
+struct Planes {                              // plane p of slot i = base[p * stride + i]
+    float* base; long long stride;
+    HRT_D float ldf(int p, long long i) const { return base[p * stride + i]; }
+    HRT_D int ldi(int p, long long i) const { return __float_as_int(base[p * stride + i]); }
+    HRT_D void stf(int p, long long i, float v) const { base[p * stride + i] = v; }
+    HRT_D void sti(int p, long long i, int v) const { base[p * stride + i] = __int_as_float(v); }
+    HRT_D F3 ld3(int p, long long i) const { return mk3(ldf(p, i), ldf(p + 1, i), ldf(p + 2, i)); }
+    HRT_D void st3(int p, long long i, F3 v) const { stf(p, i, v.x); stf(p + 1, i, v.y); stf(p + 2, i, v.z); }
+};
+
+// vertex state (buffers A / B, ping-pong per bounce)
+enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG = 18, V_PID = 19, V_MAT = 20, V_IOR = 21, V_PLANES = 22 };
+// ray request written by wf_shade for the same slot
+enum { R_O = 0, R_D = 3, R_T = 6, R_RNG = 9, R_FLG = 10, R_PLANES = 11 };
+enum { RF_DEAD = 1, RF_WROTE = 2 };          // R_FLG / V_MAT(bit 16+) flags
+// shadow request (compacted per range)
+enum { S_O = 0, S_D = 3, S_ADD = 6, S_SLOT = 9, S_PLANES = 10 };
+// reservoir staging per path id
+enum { G_L = 0, G_WI = 3, G_PDF = 6, G_W = 7, G_WSUM = 8, G_M = 9, G_LID = 10, G_FLAG = 11, G_PLANES = 12 };
+
+struct WfBuffers {
+    Planes A, B, R, SQ;          // stride = cap
+    Planes sampleLi;             // 3 planes, indexed by path id
+    Planes stage;                // G_PLANES planes, indexed by path id
+    Planes accum;                // 3 planes over pixel ordinals (Lframe carried across sample batches)
+    int* cntA;                   // [depth][range] live paths of a range at a depth
+    int* cntS;                   // [depth][range] shadow requests
+    int nRanges;
+};
+
+struct WfGeom {
+    int nOrd;                    // pixel ordinals of this tile (multiple of 64: 8x8 wave tiles)
+    int tilesX8;                 // 8-pixel tiles per row
+    int batchStart, batchCount;  // samples [batchStart, batchStart+batchCount) of spp
+    int lastBatch;
+};
+
+// pixel ordinal -> global pixel; ordinals enumerate 8x8 tiles of the device's strips row-major
+HRT_D bool ord_pixel(const WfGeom& g, const FrameK& k, int ord, int& x, int& y)
+{
+    int tile = ord >> 6, lane = ord & 63;
+    int ts = tile / g.tilesX8, tx = tile - ts * g.tilesX8;
+    x = tx * 8 + (lane & 7);
+    y = k.row_begin + (ts * k.strip_n + k.strip_i) * 8 + (lane >> 3);
+    return x < k.width && y < k.row_end;
+}
+
+// wave-local stable compaction: slot offset of this lane among the keepers, and their number
+HRT_D int wave_prefix(bool keep, int& total)
+{
+    unsigned long long m = __ballot(keep);
+    total = __popcll(m);
+    return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+
+// ------------------------------------------------------------------ init: G-buffer -> depth-0 vertices
+template <bool COUNT>
+HRT_D void wf_init_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const WfBuffers& W, int range)
+{
+    const int lane = threadIdx.x & 63;
+    const long long base = (long long)range * kRange;
+    const long long nPaths = (long long)g.batchCount * g.nOrd;
+    int outCount = 0;
+    for (int it = 0; it < kRange / 64; it++)
+    {
+        long long pid = base + it * 64 + lane;
+        bool live = false;
+        int index = 0, x = 0, y = 0, s = 0;
+        if (pid < nPaths)
+        {
+            s = (int)(pid / g.nOrd);
+            int ord = (int)(pid - (long long)s * g.nOrd);
+            if (ord_pixel(g, k, ord, x, y))
+            {
+                index = y * k.width + x;
+                live = gb.hitMask[index] != 0;
+            }
+            W.sampleLi.st3(0, pid, mk3(0.f, 0.f, 0.f));      // maxDepth == 0 leaves Li = 0 (RTRay.cs:228)
+            W.stage.sti(G_FLAG, pid, 0);
+        }
+        int total;
+        int off = wave_prefix(live, total);
+        if (live)
+        {
+            long long slot = base + outCount + off;
+            const F3 gpos = ld3(&gb.worldPos[index]);
+            const int packedMat = gb.matId[index];
+            W.A.st3(V_POS, slot, gpos);
+            W.A.st3(V_NRM, slot, normalize(ld3(&gb.normalWS[index])));            // :222
+            W.A.st3(V_ALB, slot, ld3(&gb.baseColor[index]));
+            W.A.st3(V_IDIR, slot, normalize(gpos - cv3(k.cam.origin)));           // ViewDirFromCam :230
+            W.A.st3(V_T, slot, mk3(1.f, 1.f, 1.f));
+            W.A.st3(V_LI, slot, mk3(0.f, 0.f, 0.f));
+            SeedBase sb = seed_base((uint32_t)(index % hrt_imax(1, k.width)), (uint32_t)(index / hrt_imax(1, k.width)), k.frame, 0xC0FFEEu, k.rngLockNoise);
+            W.A.sti(V_RNG, slot, (int)rng_for_sample(sb, (uint32_t)(g.batchStart + s)).s);
+            W.A.sti(V_PID, slot, (int)pid);
+            W.A.sti(V_MAT, slot, packedMat & 0xFFFF);
+            W.A.stf(V_IOR, slot, (float)((packedMat >> 16) & 0xFFFF) / 1000.f);   // I16ToFloat :226
+        }
+        outCount += total;
+    }
+    if (lane == 0) W.cntA[range] = outCount;
+}
+
+// ------------------------------------------------------------------ shade: vertex -> ray requests (RTRay.cs:235-312)
+template <bool COUNT>
+HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const DReservoir& resPrev, long long nPix,
+                         const WfBuffers& W, const Planes& V, int depth, int range, Cnt<COUNT>& C)
+{
+    const int lane = threadIdx.x & 63;
+    const long long base = (long long)range * kRange;
+    const int n = W.cntA[depth * W.nRanges + range];
+    int sqCount = 0;
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int i = it * 64 + lane;
+        const bool valid = i < n;
+        const long long slot = base + i;
+        bool wantShadow = false;
+        F3 so = mk3(0.f, 0.f, 0.f), sd = so, sadd = so;
+        if (valid)
+        {
+            const F3 pos = V.ld3(V_POS, slot), nrm = V.ld3(V_NRM, slot), alb = V.ld3(V_ALB, slot), I = V.ld3(V_IDIR, slot);
+            F3 T = V.ld3(V_T, slot);
+            Rng rng; rng.s = (uint32_t)V.ldi(V_RNG, slot);
+            const int mat = V.ldi(V_MAT, slot);
+            const int shade = mat & 0xFFFF;
+            int flg = (mat >> 16) & RF_WROTE;
+            Ray ray;
+            if (shade == HRT_SHADING_MIRROR)
+            {   // :235-244
+                F3 dirR = I - nrm * (2.f * dot(I, nrm));
+                ray = ray_with_normal_offset(pos, nrm, dirR);
+                T = T * alb;
+            }
+            else if (shade == HRT_SHADING_GLASS)
+            {   // :246-275
+                const float ior = V.ldf(V_IOR, slot);
+                F3 Nuse = nrm;
+                bool outside = dot(I, nrm) < 0.f;
+                if (!outside) Nuse = Nuse * -1.f;
+                float iorUse = ior > 0.f ? ior : 1.5f;
+                float etaI = outside ? 1.f : iorUse;
+                float etaT = outside ? iorUse : 1.f;
+                F3 dirR = I - Nuse * (2.f * dot(I, Nuse));
+                float eta = etaI / etaT;
+                float cosIr = -dot(I, Nuse);
+                float kk = 1.f - eta * eta * (1.f - cosIr * cosIr);
+                bool refrOk = !(kk < 0.f);
+                F3 dirT = mk3(0.f, 0.f, 0.f);
+                if (refrOk) dirT = normalize(I * eta + Nuse * (eta * cosIr - hrt_sqrt(kk)));
+                float cosI = hrt_abs(dot(I, Nuse));
+                float r0 = (etaI - etaT) / (etaI + etaT);
+                r0 = r0 * r0;
+                float om = 1.f - cosI;
+                float om2 = om * om;
+                float Fr = r0 + (1.f - r0) * (om2 * om2 * om);
+                float xi = rng.next_f();
+                bool reflect = (!refrOk || xi < Fr);
+                ray = reflect ? ray_with_normal_offset(pos, Nuse, dirR) : ray_with_normal_offset(pos, -Nuse, dirT);
+                if (refrOk && xi >= Fr)
+                {
+                    F3 tint = (alb.x == 0.f && alb.y == 0.f && alb.z == 0.f) ? mk3(1.f, 1.f, 1.f) : alb;
+                    float etaScale = (etaI * etaI) / (etaT * etaT);
+                    T = T * tint * etaScale;
+                }
+            }
+            else
+            {   // :277-317
+                const int pid = V.ldi(V_PID, slot);
+                const int ord = pid % g.nOrd;
+                int x, y;
+                ord_pixel(g, k, ord, x, y);
+                const int index = y * k.width + x;
+                Frame fr = make_frame(nrm);
+                Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !(flg & RF_WROTE), pos, fr, alb, rng, C);
+                if (r.m > 0 && r.wSum > 0.f && r.w > 0.f)
+                {
+                    F3 wiSel = r.wi;
+                    int lidSel = r.lightId == 2 ? 2 : 1;
+                    float nlSel = hrt_fmax(0.f, dot(nrm, wiSel));
+                    if (nlSel > 0.f)
+                    {
+                        Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
+                        float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
+                        F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
+                        F3 f_over_p = alb * LiSel * ((nlSel / pdfSel) * kINV_PI);
+                        float Wt = r.wSum / (float)hrt_imax(1, r.m) / hrt_fmax(kEPS_MIN, r.w);
+                        wantShadow = true;
+                        so = sray.o; sd = sray.d;
+                        sadd = T * (f_over_p * Wt);          // added to Li by wf_shadow iff unoccluded (:286/:291)
+                    }
+                }
+                if (!(flg & RF_WROTE))
+                {   // first diffuse vertex of this sample: stage the reservoir (resCur.Write :292-296)
+                    W.stage.st3(G_L, pid, r.L); W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, r.pdf);
+                    W.stage.stf(G_W, pid, r.w); W.stage.stf(G_WSUM, pid, r.wSum); W.stage.sti(G_M, pid, r.m);
+                    W.stage.sti(G_LID, pid, r.lightId); W.stage.sti(G_FLAG, pid, 1);
+                    flg |= RF_WROTE;
+                }
+                F3 wi = sample_hemisphere_cosine(fr, rng);
+                ray = ray_with_normal_offset(pos, nrm, wi);
+                T = T * alb;
+                if (depth >= 3)
+                {   // :306-312
+                    float maxC = hrt_fmax(T.x, hrt_fmax(T.y, T.z));
+                    maxC = hrt_clamp(maxC, 0.05f, 0.98f);
+                    if (rng.next_f() > maxC)
+                    {   // throughput = 0; break  -> the path ends with its current Li (+ this vertex's direct light)
+                        flg |= RF_DEAD;
+                    }
+                    else T = T * (1.0f / maxC);
+                }
+            }
+            W.R.st3(R_O, slot, ray.o); W.R.st3(R_D, slot, ray.d); W.R.st3(R_T, slot, T);
+            W.R.sti(R_RNG, slot, (int)rng.s); W.R.sti(R_FLG, slot, flg);
+        }
+        int total;
+        int off = wave_prefix(wantShadow, total);
+        if (wantShadow)
+        {
+            long long q = base + sqCount + off;
+            W.SQ.st3(S_O, q, so); W.SQ.st3(S_D, q, sd); W.SQ.st3(S_ADD, q, sadd); W.SQ.sti(S_SLOT, q, (int)(slot - base));
+        }
+        sqCount += total;
+    }
+    if (lane == 0) W.cntS[depth * W.nRanges + range] = sqCount;
+}
+
+// ------------------------------------------------------------------ shadow: Li += T * direct where visible (:518-539)
+template <class TR, bool COUNT>
+HRT_D void wf_shadow_wave(const TR& tr, const WfBuffers& W, const Planes& V, int depth, int range, Cnt<COUNT>& C)
+{
+    const int lane = threadIdx.x & 63;
+    const long long base = (long long)range * kRange;
+    const int n = W.cntS[depth * W.nRanges + range];
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int j = it * 64 + lane;
+        if (j < n)
+        {
+            const long long q = base + j;
+            Ray r; r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d);
+            if (!tr.template occluded<COUNT>(r, 1e29f, C))
+            {
+                const long long slot = base + W.SQ.ldi(S_SLOT, q);
+                V.st3(V_LI, slot, V.ld3(V_LI, slot) + W.SQ.ld3(S_ADD, q));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ closest: next vertex or sky (TraceNext :659-671, :241-243)
+template <class TR, bool COUNT>
+HRT_D void wf_closest_wave(const TR& tr, const FrameK& k, const WfBuffers& W, const Planes& V, const Planes& Vn, int depth, int range, Cnt<COUNT>& C)
+{
+    const int lane = threadIdx.x & 63;
+    const long long base = (long long)range * kRange;
+    const int n = W.cntA[depth * W.nRanges + range];
+    const bool lastDepth = depth + 1 >= k.maxDepth;
+    int outCount = 0;
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int i = it * 64 + lane;
+        const long long slot = base + i;
+        // only the ray is live across the walk; throughput, radiance, RNG and ids are fetched after it
+        bool survive = false, missed = false, dead = false;
+        Hit h; Ray r;
+        if (i < n)
+        {
+            dead = (W.R.ldi(R_FLG, slot) & RF_DEAD) != 0;        // Russian roulette ended the path in wf_shade
+            if (!dead)
+            {
+                r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = inv_dir(r.d);
+                if (!tr.template closest<COUNT>(r, h, C)) missed = true;
+                else survive = !lastDepth;
+            }
+            if (!survive)
+            {   // the path ends here: final Li (+ T * sky on a miss, :241-243)
+                const int pid = V.ldi(V_PID, slot);
+                F3 Li = V.ld3(V_LI, slot);
+                if (missed) Li = Li + W.R.ld3(R_T, slot) * sky(k, r.d);
+                W.sampleLi.st3(0, pid, Li);
+            }
+        }
+        int total;
+        int off = wave_prefix(survive, total);
+        if (survive)
+        {
+            long long o = base + outCount + off;
+            Vn.st3(V_POS, o, r.o + r.d * h.t);
+            Vn.st3(V_NRM, o, normalize(h.n));
+            Vn.st3(V_ALB, o, h.albedo);
+            Vn.st3(V_IDIR, o, r.d);
+            Vn.st3(V_T, o, W.R.ld3(R_T, slot));
+            Vn.st3(V_LI, o, V.ld3(V_LI, slot));
+            Vn.sti(V_RNG, o, W.R.ldi(R_RNG, slot));
+            Vn.sti(V_PID, o, V.ldi(V_PID, slot));
+            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((W.R.ldi(R_FLG, slot) & RF_WROTE) << 16));
+            Vn.stf(V_IOR, o, h.ior);
+        }
+        outCount += total;
+    }
+    if (lane == 0) W.cntA[(depth + 1) * W.nRanges + range] = outCount;
+}
+
+// ------------------------------------------------------------------ resolve: ordered sample sum, reservoir hand-off, framebuffer store (:320-324)
+HRT_D void wf_resolve_pixel(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const DFramebuffer& fb, const DReservoir& resCur,
+                            const WfBuffers& W, int ord)
+{
+    int x, y;
+    if (!ord_pixel(g, k, ord, x, y)) return;
+    const int index = y * k.width + x;
+    if (index == 0 && fb.cameraId && g.batchStart == 0) fb.cameraId[0] = k.debugCamSeq;
+    F3 Lframe = g.batchStart == 0 ? mk3(0.f, 0.f, 0.f) : W.accum.ld3(0, ord);
+    const int hitMask = gb.hitMask[index];
+    if (hitMask == 0)
+    {
+        F3 c = safe_color(sky(k, primary_ray(k, x, y).d));                    // :214-219
+        for (int s = 0; s < g.batchCount; s++) Lframe = Lframe + c;
+    }
+    else
+    {
+        int winner = -1;
+        for (int s = 0; s < g.batchCount; s++)
+        {
+            long long pid = (long long)s * g.nOrd + ord;
+            Lframe = Lframe + safe_color(W.sampleLi.ld3(0, pid));             // :320, in sample order
+            if (W.stage.ldi(G_FLAG, pid)) winner = s;                          // last sample that reached a diffuse vertex
+        }
+        if (winner >= 0)
+        {
+            long long pid = (long long)winner * g.nOrd + ord;
+            resCur.L[index] = to3(W.stage.ld3(G_L, pid)); resCur.wi[index] = to3(W.stage.ld3(G_WI, pid));
+            resCur.pdf[index] = W.stage.ldf(G_PDF, pid); resCur.w[index] = W.stage.ldf(G_W, pid);
+            resCur.wSum[index] = W.stage.ldf(G_WSUM, pid); resCur.lightId[index] = W.stage.ldi(G_LID, pid);
+            resCur.m[index] = W.stage.ldi(G_M, pid);
+        }
+    }
+    if (!g.lastBatch) { W.accum.st3(0, ord, Lframe); return; }
+    F3 Lout = Lframe * (1.0f / (float)hrt_imax(1, k.spp));
+    if (fb.radiance) fb.radiance[index] = to3(Lout);
+    fb.color[index] = pack_rgba8(Lout);
+    fb.depth[index] = cam_distance(k, ld3(&gb.worldPos[index]));
+    fb.objectId[index] = gb.objId[index];
+}
+
+} // namespace hrt

@@ -64,12 +64,22 @@ def _quirk_scene(b):
     b.rebuild_tlas()
 
 
+# the four kernel organisations of the library must all reproduce the oracle
+MODES = {
+    "stream_packed": T.FLAG_COUNTERS,                                                   # default product path
+    "mega_packed": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL,
+    "stream_reflayout": T.FLAG_COUNTERS | T.FLAG_REFERENCE_LAYOUT,
+    "mega_reflayout": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL | T.FLAG_REFERENCE_LAYOUT,
+}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("name", list(CASES))
-def test_frame_matches_oracle(orc, renderer, name):
+def test_frame_matches_oracle(orc, renderer, name, mode):
     builder, cfg, w, h, spp = CASES[name]
     builder = builder or _quirk_scene
     ref, ost, _ = H.oracle_frame(orc, builder, cfg, w, h, spp)
-    got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp)
+    got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, flags=MODES[mode])
     H.assert_outputs_equal(ref, got, names=[n for n in ref if not n.startswith("res_")])
     _check_radiance_tolerance(ref, got)
     # reservoirs: resCur is written only where a diffuse vertex was reached; both start from zeros
@@ -87,7 +97,8 @@ def test_counters_off_gives_same_pixels(renderer):
     assert sb.counters_valid == 0 and sb.k[1].rays_closest == 0
 
 
-def test_restir_reuse_over_frames(orc, renderer):
+@pytest.mark.parametrize("mode", ["stream_packed", "mega_packed"])
+def test_restir_reuse_over_frames(orc, renderer, mode):
     """Temporal + spatial reuse, frames 0..3, static camera: reservoirs ping-pong A/B by frame parity
     (Framebuffer.cs:132-145) on both sides; every frame's outputs and reservoirs must match."""
     builder, cfg, w, h, spp = scenes.build_textured_test_scene, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0)), 160, 120, 2
@@ -98,7 +109,7 @@ def test_restir_reuse_over_frames(orc, renderer):
     for f in range(4):
         prev, cur = (B, A) if f % 2 == 0 else (A, B)
         ref, ost, _ = H.oracle_frame(orc, builder, cfg, w, h, spp, frame=f, reuse=True, prev=prev, cur=cur)
-        got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, frame=f, reuse=True, commit=False)
+        got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, frame=f, reuse=True, commit=False, flags=MODES[mode])
         H.assert_outputs_equal(ref, got)
         assert gst.k[1].as_dict() == ost.k[1].as_dict()
         imports += gst.k[1].reuse_imports

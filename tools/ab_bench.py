@@ -22,7 +22,7 @@ for cid in [int(c) for c in args.configs.split(",")]:
     st = r.render_params(p, None, flags=T.FLAG_COUNTERS)
     rays = sum(st.k[i].rays_closest + st.k[i].rays_shadow for i in range(2))
     line = "cfg%d %dx%d spp%d rays %.1fM build %.2fs upload %.2fs |" % (cid, p.width, p.height, p.spp, rays / 1e6, tb, tu)
-    modes = [("packed", 0)] + ([("reflayout", T.FLAG_REFERENCE_LAYOUT)] if args.ref else [])
+    modes = [("stream", 0), ("mega", T.FLAG_MEGAKERNEL)] + ([("mega+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL), ("stream+reflayout", T.FLAG_REFERENCE_LAYOUT)] if args.ref else [])
     for name, fl in modes:
         r.render_params(p, None, flags=fl)
         for _ in range(args.frames):
@@ -34,6 +34,6 @@ for cid in [int(c) for c in args.configs.split(",")]:
     if args.check:
         names = ["color", "depth", "objectId", "radiance", "gb_worldPos", "gb_normalWS", "gb_baseColor", "gb_matId", "gb_objId", "gb_hitMask", "res_L", "res_m"]
         a, oa = T.alloc_outputs(p.width, p.height, names); b, ob = T.alloc_outputs(p.width, p.height, names)
-        r.reset_history(); r.render_params(p, oa); r.reset_history(); r.render_params(p, ob, flags=T.FLAG_REFERENCE_LAYOUT)
+        r.reset_history(); r.render_params(p, oa); r.reset_history(); r.render_params(p, ob, flags=T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL)
         bad = {k: int(np.count_nonzero(~((a[k] == b[k]) | ((a[k] != a[k]) & (b[k] != b[k]))))) for k in a}
-        print("   packed vs reference-layout mismatches:", {k: v for k, v in bad.items() if v} or "none", flush=True)
+        print("   stream/packed vs mega/reference-layout mismatches:", {k: v for k, v in bad.items() if v} or "none", flush=True)
