@@ -124,6 +124,35 @@ hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigne
     C.flush(counters);
 }
 
+// persistent-wave walk kernels (packed layout only) + the finish kernel that shades the winners
+template <int FEAT, bool COUNT>
+__global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
+hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_walk_shadow_wave<FEAT, COUNT>(tr, W, vsel ? W.B : W.A, depth, range, C);
+    C.flush(counters);
+}
+
+template <int FEAT, bool COUNT>
+__global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
+hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_walk_closest_wave<FEAT, COUNT>(tr, W, depth, range, C);
+    C.flush(counters);
+}
+
+template <int FEAT, bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_wf_finish_kernel(TracerPackedT<FEAT> tr, FrameK k, WfBuffers W, int vsel, int depth)
+{
+    int range = wf_range(W.nRanges);
+    if (range >= 0) wf_finish_wave<FEAT, COUNT>(tr, k, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range);
+}
+
 __global__ void __launch_bounds__(256)
 hrt_wf_resolve_kernel(FrameK k, WfGeom g, DGBuffer gb, DFramebuffer fb, DReservoir resCur, WfBuffers W)
 {
@@ -519,6 +548,9 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nR
     return HRT_OK;
 }
 
+template <class TR> struct PackedFeat { static constexpr int value = -1; };
+template <int F> struct PackedFeat<TracerPackedT<F>> { static constexpr int value = F; };
+
 template <class TR>
 int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, const TileMap& tm, int width,
                    const DReservoir& resPrev, const DReservoir& resCur, long long nPix, bool count, bool mega)
@@ -557,17 +589,36 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         for (int depth = 0; depth < k.maxDepth; depth++)
         {
             const int vsel = depth & 1;
-            if (count)
-            {
-                hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
-                hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+            if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            if constexpr (PackedFeat<TR>::value >= 0)
+            {   // packed layout: persistent-wave walks + finish
+                constexpr int F = PackedFeat<TR>::value;
+                if (count)
+                {
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), gridR, block, 0, d.stream, tr, W, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), gridR, block, 0, d.stream, tr, W, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                }
             }
             else
-            {
-                hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
-                hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+            {   // reference layout: one-ray-per-lane walks
+                if (count)
+                {
+                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+                }
             }
         }
         hipLaunchKernelGGL(hrt_wf_resolve_kernel, gridP, block, 0, d.stream, k, g, d.gb, d.fb, resCur, W);

@@ -273,10 +273,16 @@ struct TracerPackedT {
             cur = lskip;
         }
 
+        return finish_hit(wray, bestT, bestTObj, bestSlot, bestPrim, best);
+    }
+
+    // ---- shade the winner of a walk once (normal :534-535/:556, albedo :146-159/:210-223, world normal :71).
+    // Pure function of (ray, winner): the streamed pipeline calls it from a separate kernel.
+    HRT_D bool finish_hit(const Ray& wray, float bestT, float bestTObj, int bestSlot, int bestPrim, Hit& best) const
+    {
         best.t = bestT; best.n = mk3(0.f, 0.f, 0.f); best.albedo = mk3(1.f, 1.f, 1.f); best.objId = -1; best.shade = 0; best.ior = 1.f;
         if (!(bestT < 1e29f)) return false;
 
-        // ---- shade the winner once (normal :534-535/:556, albedo :146-159/:210-223, world normal :71)
         FInst f = P.finst[bestSlot];
         const int flags = wbits(f.a);
         Tex tex(S);

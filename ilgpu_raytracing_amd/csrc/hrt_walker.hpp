@@ -1,0 +1,252 @@
+// hrt_walker.hpp -- persistent-wave BVH walker with ballot/prefix refill of idle lanes.
+//
+// Measured on the one-ray-per-lane walk (profiles/r01_pmc_config3_*): the traversal kernels are
+// VALU-bound but only ~16 % of the lanes of an executed instruction are live -- a wave runs
+// until its LONGEST ray is done (sky rays leave after a few nodes, grazing rays visit
+// hundreds).  Here a wave owns a queue of n rays and keeps its 64 lanes full: each lane carries
+// a resumable walk state (which tree, which node, which leaf entry), and whenever >= kRefillMin
+// lanes have finished, one __ballot + popcount prefix hands each of them the next unfetched ray
+// of the queue.  Every iteration all walking lanes take a node step together (TLAS and BLAS
+// nodes share the code: same 32-byte NodeQ, same box test), then lanes standing on a leaf entry
+// take one primitive step.  A ray's sequence of node visits, box tests and primitive tests is
+// exactly the reference's (SceneDeviceViews.cs:30-327), so hits, tie-breaks and work counters
+// are unchanged; only the interleaving across rays differs.
+//
+// The walker produces raw winners (t, leaf slot, primitive) or an occlusion bit; shading the
+// winner (TracerPackedT::finish_hit) runs afterwards at full lane occupancy.
+#pragma once
+#include "hrt_trace_packed.hpp"
+
+namespace hrt {
+
+enum { M_IDLE = 0, M_TLAS = 1, M_TLEAF = 2, M_BLAS = 3, M_BLEAF = 4, M_DONE = 5 };
+constexpr int kRefillMin = 16;      // refill when at least this many lanes are idle (or none is active)
+constexpr int kNodeBurst = 6;       // max node steps per iteration while most lanes are still walking
+
+struct WalkResult { float t, tObj; int slot, prim; bool occluded; };
+
+// FEAT as in TracerPackedT.  ANY = shadow rays (any hit, tMax) vs closest hit.
+// fetch(i, ray, tMax) loads ray i of the queue (false: entry carries no ray); done(i, result) consumes its result.
+template <int FEAT, bool ANY, bool COUNT, class Fetch, class Done>
+HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done done, Cnt<COUNT>& C)
+{
+    constexpr bool kGeneral = (FEAT & 1) != 0;
+    constexpr bool kAlpha = (FEAT & 2) != 0;
+    __shared__ float park_mem[kGeneral ? 9 : 1][256];
+    RayPark park; park.sh = park_mem;
+    const DPacked& P = tr.P;
+    const DScene& S = tr.S;
+    Tex tex(S);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    int nextRay = 0;                 // wave-uniform: first unfetched ray
+    int mode = M_IDLE, rayIdx = -1;
+    Ray w;                           // ray in use: world ray (TLAS modes) or object ray (BLAS modes; world ray parked in LDS)
+    w.o = w.d = w.inv = mk3(0.f, 0.f, 0.f);
+    float tMaxW = 0.f;               // ANY: world tMax
+    float bestT = 1e30f, bestTObj = 0.f; int bestSlot = -1, bestPrim = -1;     // closest
+    bool occl = false;
+    int cur = 0, li = 0, lend = 0, lskip = kEnd;          // TLAS walk / leaf iteration
+    int bj = 0, bend = 0, bskip = kEnd;                   // BLAS leaf iteration
+    int blasEnd = 0, iflags = 0, islot = 0; float iscale = 1.f, tObj = 1e30f; int iprim = -1;   // instance being walked
+
+    for (;;)
+    {
+        // ---------------- refill idle lanes from the queue
+        {
+            unsigned long long idle = __ballot(mode == M_IDLE);
+            int nIdle = __popcll(idle);
+            if (nextRay < n)
+            {
+                if (nIdle >= kRefillMin || nIdle == 64)
+                {
+                    int my = nextRay + __popcll(idle & lt);
+                    if (mode == M_IDLE && my < n)
+                    {
+                        rayIdx = my;
+                        bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false;
+                        if (fetch(my, w, tMaxW)) { C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS; }
+                        else mode = M_DONE;                   // queue entry without a ray (path already ended)
+                    }
+                    nextRay += nIdle;
+                }
+            }
+            else if (nIdle == 64) break;         // queue drained and every lane finished
+        }
+
+        // ---------------- node steps: TLAS and BLAS nodes alike
+        for (int burst = 0; burst < kNodeBurst; burst++)
+        {
+            const bool walking = (mode == M_TLAS) || (kGeneral && mode == M_BLAS);
+            const int nWalk = __popcll(__ballot(walking));
+            if (nWalk == 0 || (burst > 0 && nWalk < 24)) break;
+            if (walking)
+            {
+                const bool top = !kGeneral || mode == M_TLAS;
+                const NodeQ* nodes = top ? P.tlas : P.blas;
+                NodeQ nd = nodes[cur];
+                C.inc(C_NODE_VISITS);
+                const float lim = top ? (ANY ? tMaxW : bestT) : (ANY ? tMaxW * iscale : tObj);
+                int sk = wbits(nd.hi);
+                const int cnt = (int)((unsigned)sk >> 28);
+                sk &= kEnd;
+                if (!hit_box(w, nd.lo, nd.hi, 0.001f, lim)) cur = sk;
+                else if (cnt > 0)
+                {
+                    if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
+                    else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
+                }
+                else cur = wbits(nd.lo) & kEnd;
+            }
+            // walk ends
+            if (kGeneral && mode == M_BLAS && !(cur < blasEnd))
+            {   // BLAS exhausted: fold the instance result into the world result (:65-77), back to the TLAS leaf
+                if (!ANY && tObj < 1e29f)
+                {
+                    float tWorld = tObj / iscale;
+                    if (tWorld < bestT) { bestT = tWorld; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; }
+                }
+                w = park.get();
+                mode = M_TLEAF;
+            }
+            if (mode == M_TLEAF && li == lend) { cur = lskip; mode = M_TLAS; }
+            if (mode == M_TLAS && cur == kEnd) mode = M_DONE;
+        }
+
+        // ---------------- one TLAS leaf entry
+        if (mode == M_TLEAF)
+        {
+            FInst f = P.finst[li];
+            C.inc(C_LEAF_INST);
+            const int flags = wbits(f.a);
+            if (!kGeneral || (flags & FI_FAST_SPHERE))
+            {
+                C.inc(C_NODE_VISITS);                        // the one-node BLAS of the instance
+                const float lim = ANY ? tMaxW : 1e30f;
+                if (hit_box(w, f.a, f.b, 0.001f, lim))
+                {
+                    C.inc(C_SPHERE_TESTS);
+                    float t;
+                    if (hit_sphere_t(w, xyz(f.c), f.c.w, t) && t > 0.001f && t < lim)
+                    {
+                        if (ANY) { occl = true; mode = M_DONE; }
+                        else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); }
+                    }
+                }
+                li++;
+            }
+            else
+            {   // general instance: park the world ray, walk its BLAS with the object-space ray
+                islot = li; iflags = flags; iscale = f.c.z;
+                cur = __float_as_int(f.c.x); blasEnd = __float_as_int(f.c.y);
+                tObj = 1e30f; iprim = -1;
+                park.put(w);
+                w = tr.object_ray(w, flags, wbits(f.b));
+                li++;
+                mode = M_BLAS;
+                if (!(cur < blasEnd)) { w = park.get(); mode = M_TLEAF; }          // empty BLAS
+            }
+            if (mode == M_TLEAF && li == lend) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
+        }
+
+        // ---------------- one BLAS leaf entry
+        if (kGeneral && mode == M_BLEAF)
+        {
+            const float lim = ANY ? tMaxW * iscale : tObj;
+            if (iflags & FI_SPHERESET)
+            {
+                int p = S.spherePrimIdx[bj];
+                const hrt_sphere* sp = &S.spheres[p];
+                C.inc(C_SPHERE_TESTS);
+                float t;
+                if (hit_sphere_t(w, cv3(sp->center), sp->radius, t) && t > 0.001f && t < lim)
+                {
+                    if (ANY) { occl = true; mode = M_DONE; }
+                    else { tObj = t; iprim = p; }
+                }
+            }
+            else
+            {
+                FTri trr = P.ftri[bj];
+                C.inc(C_TRI_TESTS);
+                float t, bu, bv;
+                if (hit_tri_t(w, xyz(trr.v0), xyz(trr.v1), xyz(trr.v2), t, bu, bv))
+                {
+                    if (!ANY)
+                    {   // TraverseBLAS_Tri_Textured :196-227
+                        C.inc(C_TRI_MT_HITS);
+                        if (t > 0.001f && t < tObj)
+                        {
+                            C.inc(C_TRI_ACCEPTED);
+                            bool accept = true;
+                            if (kAlpha && (wbits(trr.v2) & FT_TEXTURED))
+                            {
+                                const hrt_material* mat = &S.materials[wbits(trr.v1)];
+                                int ati = mat->AlphaTexIndex;
+                                float alpha = 1.f;
+                                if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
+                                {
+                                    float uu, vv;
+                                    tr.tri_uv(wbits(trr.v0), bu, bv, uu, vv);
+                                    alpha = tex.mask_linear(S.texInfos[ati], uu, vv);
+                                }
+                                accept = !(alpha < mat->AlphaCutoff);
+                            }
+                            if (accept) { tObj = t; iprim = bj; }
+                        }
+                    }
+                    else if (!(t <= 0.001f || t >= lim))
+                    {   // AnyHit_Tri_Textured :292-317
+                        C.inc(C_TRI_MT_HITS);
+                        bool blocked = true;
+                        if (kAlpha && (wbits(trr.v2) & FT_TEXTURED))
+                        {
+                            const hrt_material* mat = &S.materials[wbits(trr.v1)];
+                            int ati = mat->AlphaTexIndex;
+                            if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
+                            {
+                                C.inc(C_TRI_ACCEPTED);
+                                float uu, vv;
+                                tr.tri_uv(wbits(trr.v0), bu, bv, uu, vv);
+                                hrt_tex_info ainfo = S.texInfos[ati];
+                                float aPoint = tex.mask_point(ainfo, uu, vv);
+                                float cutoff = mat->AlphaCutoff;
+                                if (aPoint < cutoff - 0.10f) blocked = false;
+                                else if (aPoint >= cutoff + 0.10f) blocked = true;
+                                else blocked = !(tex.mask_linear(ainfo, uu, vv) < cutoff);
+                            }
+                        }
+                        if (blocked) { occl = true; mode = M_DONE; }
+                    }
+                }
+            }
+            bj++;
+            if (mode == M_BLEAF && bj == bend)
+            {
+                cur = bskip; mode = M_BLAS;
+                if (!(cur < blasEnd))
+                {
+                    if (!ANY && tObj < 1e29f)
+                    {
+                        float tWorld = tObj / iscale;
+                        if (tWorld < bestT) { bestT = tWorld; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; }
+                    }
+                    w = park.get();
+                    mode = M_TLEAF;
+                    if (li == lend) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
+                }
+            }
+        }
+
+        // ---------------- retire finished rays
+        if (mode == M_DONE)
+        {
+            WalkResult r; r.t = bestT; r.tObj = bestTObj; r.slot = bestSlot; r.prim = bestPrim; r.occluded = occl;
+            done(rayIdx, r);
+            mode = M_IDLE;
+        }
+    }
+}
+
+} // namespace hrt

@@ -33,6 +33,7 @@
 // order, RNG state carried in a plane, so results stay bit-identical to the oracle.
 #pragma once
 #include "hrt_device.hpp"
+#include "hrt_walker.hpp"
 
 namespace hrt {
 
@@ -51,7 +52,7 @@ struct Planes {                              // plane p of slot i = base[p * str
 // vertex state (buffers A / B, ping-pong per bounce)
 enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG = 18, V_PID = 19, V_MAT = 20, V_IOR = 21, V_PLANES = 22 };
 // ray request written by wf_shade for the same slot
-enum { R_O = 0, R_D = 3, R_T = 6, R_RNG = 9, R_FLG = 10, R_PLANES = 11 };
+enum { R_O = 0, R_D = 3, R_T = 6, R_RNG = 9, R_FLG = 10, R_HT = 11, R_HSLOT = 12, R_HPRIM = 13, R_HTOBJ = 14, R_PLANES = 15 };   // R_H*: raw winner of the closest-hit walk
 enum { RF_DEAD = 1, RF_WROTE = 2 };          // R_FLG / V_MAT(bit 16+) flags
 // shadow request (compacted per range)
 enum { S_O = 0, S_D = 3, S_ADD = 6, S_SLOT = 9, S_PLANES = 10 };
@@ -317,6 +318,104 @@ HRT_D void wf_closest_wave(const TR& tr, const FrameK& k, const WfBuffers& W, co
             }
             if (!survive)
             {   // the path ends here: final Li (+ T * sky on a miss, :241-243)
+                const int pid = V.ldi(V_PID, slot);
+                F3 Li = V.ld3(V_LI, slot);
+                if (missed) Li = Li + W.R.ld3(R_T, slot) * sky(k, r.d);
+                W.sampleLi.st3(0, pid, Li);
+            }
+        }
+        int total;
+        int off = wave_prefix(survive, total);
+        if (survive)
+        {
+            long long o = base + outCount + off;
+            Vn.st3(V_POS, o, r.o + r.d * h.t);
+            Vn.st3(V_NRM, o, normalize(h.n));
+            Vn.st3(V_ALB, o, h.albedo);
+            Vn.st3(V_IDIR, o, r.d);
+            Vn.st3(V_T, o, W.R.ld3(R_T, slot));
+            Vn.st3(V_LI, o, V.ld3(V_LI, slot));
+            Vn.sti(V_RNG, o, W.R.ldi(R_RNG, slot));
+            Vn.sti(V_PID, o, V.ldi(V_PID, slot));
+            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((W.R.ldi(R_FLG, slot) & RF_WROTE) << 16));
+            Vn.stf(V_IOR, o, h.ior);
+        }
+        outCount += total;
+    }
+    if (lane == 0) W.cntA[(depth + 1) * W.nRanges + range] = outCount;
+}
+
+// ------------------------------------------------------------------ persistent-wave variants (packed layout): walk, then finish
+template <int FEAT, bool COUNT>
+HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int range, Cnt<COUNT>& C)
+{
+    const long long base = (long long)range * kRange;
+    const int n = W.cntS[depth * W.nRanges + range];
+    if (n == 0) return;
+    walk_queue<FEAT, true, COUNT>(tr, n,
+        [&](int j, Ray& r, float& tMax) { const long long q = base + j; r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d); tMax = 1e29f; return true; },
+        [&](int j, const WalkResult& res) {
+            if (!res.occluded)
+            {
+                const long long q = base + j;
+                const long long slot = base + W.SQ.ldi(S_SLOT, q);
+                V.st3(V_LI, slot, V.ld3(V_LI, slot) + W.SQ.ld3(S_ADD, q));
+            }
+        }, C);
+}
+
+template <int FEAT, bool COUNT>
+HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int range, Cnt<COUNT>& C)
+{
+    const long long base = (long long)range * kRange;
+    const int n = W.cntA[depth * W.nRanges + range];
+    if (n == 0) return;
+    walk_queue<FEAT, false, COUNT>(tr, n,
+        [&](int i, Ray& r, float& tMax) {
+            const long long slot = base + i;
+            tMax = 1e30f;
+            if (W.R.ldi(R_FLG, slot) & RF_DEAD) return false;
+            r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = inv_dir(r.d);
+            return true;
+        },
+        [&](int i, const WalkResult& res) {
+            const long long slot = base + i;
+            W.R.stf(R_HT, slot, res.t); W.R.sti(R_HSLOT, slot, res.slot); W.R.sti(R_HPRIM, slot, res.prim); W.R.stf(R_HTOBJ, slot, res.tObj);
+        }, C);
+}
+
+// next vertex or end of path from the raw winners (TraceNext :659-671, :241-243), with segmented compaction
+template <int FEAT, bool COUNT>
+HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const WfBuffers& W, const Planes& V, const Planes& Vn, int depth, int range)
+{
+    const int lane = threadIdx.x & 63;
+    const long long base = (long long)range * kRange;
+    const int n = W.cntA[depth * W.nRanges + range];
+    const bool lastDepth = depth + 1 >= k.maxDepth;
+    int outCount = 0;
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int i = it * 64 + lane;
+        const long long slot = base + i;
+        bool survive = false;
+        Hit h; Ray r;
+        if (i < n)
+        {
+            const bool dead = (W.R.ldi(R_FLG, slot) & RF_DEAD) != 0;
+            bool missed = false;
+            if (!dead)
+            {
+                r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = mk3(0.f, 0.f, 0.f);
+                const float ht = W.R.ldf(R_HT, slot);
+                if (!(ht < 1e29f)) missed = true;
+                else if (!lastDepth)
+                {
+                    survive = true;
+                    tr.finish_hit(r, ht, W.R.ldf(R_HTOBJ, slot), W.R.ldi(R_HSLOT, slot), W.R.ldi(R_HPRIM, slot), h);
+                }
+            }
+            if (!survive)
+            {
                 const int pid = V.ldi(V_PID, slot);
                 F3 Li = V.ld3(V_LI, slot);
                 if (missed) Li = Li + W.R.ld3(R_T, slot) * sky(k, r.d);

@@ -1,0 +1,5 @@
+import csv,glob,sys
+f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    n=r['Name']; short=n.split('(')[0].replace('void ','').replace('hrt::','')
+    print("%-62s calls %4s avg %10.1f us  total %9.2f ms  %5s%%" % (short[:62], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6, r['Percentage']))
