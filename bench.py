@@ -147,6 +147,8 @@ def main():
     p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction)
     strips = (world, rank)
     P = cfg.width * cfg.height
+    n_nodes = len(s.arrays()["tlasNodes"]) + len(s.arrays()["blasNodes"])
+    fused = n_nodes <= 256            # the library's own choice (hrt_runtime.hip kSmallSceneNodes); reported, not forced
 
     # untimed counting frame: rays + work counters of this rank's strips (deterministic)
     st = r.render_params(p, None, flags=T.FLAG_COUNTERS, strips=strips)
@@ -189,7 +191,7 @@ def main():
         value = rays_total * args.steps / dt_max / 1e6
         achieved = bytes_total / (path_ms * 1e-3) / 1e9           # GB/s over all ranks' launches (max launch time)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_config%d.json" % args.config)
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_config%d.json" % args.config)
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -203,7 +205,7 @@ def main():
             "config": {"workload": cfg.name, "description": cfg.description, "width": cfg.width, "height": cfg.height, "spp": cfg.spp,
                        "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
                        "rays_per_step": int(rays_total)},
-            "roofline": {"bound": "hbm", "kernel": "hrt_path_trace_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("hrt_path_trace_kernel (fused)" if fused else "path-trace stage, streamed: hrt_wf_{init,shade,walk_shadow,walk_closest,finish,resolve}_kernel"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_total), "launch_ms": round(path_ms, 4)},
             "extra": {"primary_kernel_ms": round(prim_ms, 4), "path_trace_kernel_ms": round(path_ms, 4),

@@ -140,6 +140,7 @@ FLAG_SKIP_PRIMARY = 2
 FLAG_REFERENCE_LAYOUT = 4
 FLAG_NO_SYNC = 8
 FLAG_MEGAKERNEL = 16
+FLAG_STREAMED = 32
 
 SHADING_LAMBERT, SHADING_MIRROR, SHADING_GLASS = 0, 1, 2
 BLAS_SPHERESET, BLAS_TRIMESH = 1, 2

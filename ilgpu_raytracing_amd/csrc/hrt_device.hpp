@@ -838,6 +838,8 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         const float gior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
         const F3 gI = normalize(gpos - cv3(k.cam.origin));
         const SeedBase sb = seed_base((uint32_t)px, (uint32_t)py, k.frame, 0xC0FFEEu, k.rngLockNoise);
+        Res lastRes; bool haveRes = false;
+        lastRes.L = lastRes.wi = mk3(0.f, 0.f, 0.f); lastRes.pdf = lastRes.w = lastRes.wSum = 0.f; lastRes.m = lastRes.lightId = 0;
 
         for (int s = 0; s < spp; s++)
         {
@@ -917,10 +919,10 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                     }
                     Li = Li + T * contrib;       // :286/:291, also when contrib == 0
                     if (!wroteReservoir)
-                    {   // resCur.Write :42-47
-                        resCur.L[index] = to3(r.L); resCur.wi[index] = to3(r.wi); resCur.pdf[index] = r.pdf;
-                        resCur.w[index] = r.w; resCur.wSum[index] = r.wSum; resCur.lightId[index] = r.lightId;
-                        resCur.m[index] = r.m;
+                    {   // resCur.Write :42-47.  Every sample's first diffuse vertex writes the same slot and only
+                        // the last write survives: keep it in registers, store once after the sample loop
+                        // (saves (spp-1) x 44 B/pixel of HBM writes).
+                        lastRes = r; haveRes = true;
                         wroteReservoir = true;
                     }
                     F3 wi = sample_hemisphere_cosine(fr, rng);
@@ -945,6 +947,12 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 I = ray.d;
             }
             Lframe = Lframe + safe_color(Li);
+        }
+        if (haveRes)
+        {
+            resCur.L[index] = to3(lastRes.L); resCur.wi[index] = to3(lastRes.wi); resCur.pdf[index] = lastRes.pdf;
+            resCur.w[index] = lastRes.w; resCur.wSum[index] = lastRes.wSum; resCur.lightId[index] = lastRes.lightId;
+            resCur.m[index] = lastRes.m;
         }
     }
 

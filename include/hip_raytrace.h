@@ -74,8 +74,9 @@ enum hrt_render_flags {
     HRT_FLAG_REFERENCE_LAYOUT = 1u << 2, /* walk the reference's own arrays (TracerRef) instead of the device-private
                                          repack: identical results, A/B baseline and fallback for scenes beyond the
                                          packed encoding (leaf count > 15)                                      */
-    HRT_FLAG_MEGAKERNEL   = 1u << 4,  /* run the path-trace launch as ONE one-pixel-per-lane kernel instead of the
-                                         streamed init/shade/shadow/closest/resolve pipeline (identical results; A/B) */
+    HRT_FLAG_MEGAKERNEL   = 1u << 4,  /* force the path-trace launch to run as ONE one-pixel-per-lane kernel      */
+    HRT_FLAG_STREAMED     = 1u << 5,  /* force the streamed init/shade/walk/finish/resolve pipeline.  Neither flag:
+                                         the library picks by scene size (tiny BVH -> fused).  Identical results.  */
     HRT_FLAG_NO_SYNC      = 1u << 3   /* enqueue only (outputs must be NULL); collect with hrt_synchronize.
                                          Up to 128 frames may be in flight; the 129th call drains first.      */
 };

@@ -66,9 +66,10 @@ def _quirk_scene(b):
 
 # the four kernel organisations of the library must all reproduce the oracle
 MODES = {
-    "stream_packed": T.FLAG_COUNTERS,                                                   # default product path
+    "auto": T.FLAG_COUNTERS,                                                            # what a host gets by default
+    "stream_packed": T.FLAG_COUNTERS | T.FLAG_STREAMED,
     "mega_packed": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL,
-    "stream_reflayout": T.FLAG_COUNTERS | T.FLAG_REFERENCE_LAYOUT,
+    "stream_reflayout": T.FLAG_COUNTERS | T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT,
     "mega_reflayout": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL | T.FLAG_REFERENCE_LAYOUT,
 }
 

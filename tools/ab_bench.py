@@ -22,7 +22,7 @@ for cid in [int(c) for c in args.configs.split(",")]:
     st = r.render_params(p, None, flags=T.FLAG_COUNTERS)
     rays = sum(st.k[i].rays_closest + st.k[i].rays_shadow for i in range(2))
     line = "cfg%d %dx%d spp%d rays %.1fM build %.2fs upload %.2fs |" % (cid, p.width, p.height, p.spp, rays / 1e6, tb, tu)
-    modes = [("stream", 0), ("mega", T.FLAG_MEGAKERNEL)] + ([("mega+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL), ("stream+reflayout", T.FLAG_REFERENCE_LAYOUT)] if args.ref else [])
+    modes = [("auto", 0), ("stream", T.FLAG_STREAMED), ("mega", T.FLAG_MEGAKERNEL)] + ([("mega+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL), ("stream+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_STREAMED)] if args.ref else [])
     for name, fl in modes:
         r.render_params(p, None, flags=fl)
         for _ in range(args.frames):
