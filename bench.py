@@ -126,10 +126,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
-    torch.cuda.set_device(local_rank)
+    # HRT_BENCH_REHEARSAL=1: functional rehearsal of the N-rank path on a 1-GPU box (all ranks share device 0,
+    # gloo instead of RCCL).  Never used for reported numbers.
+    rehearsal = os.environ.get("HRT_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     def barrier():
         if world > 1:
@@ -140,7 +147,7 @@ def main():
     if args.spp:
         cfg = scenes.Config(cfg.name + "_spp%d" % args.spp, cfg.width, cfg.height, args.spp, cfg.cam_origin, cfg.cam_lookat,
                             cfg.max_depth, cfg.vfov, cfg.description, cfg.extra)
-    r = engine.RTRenderer([local_rank])
+    r = engine.RTRenderer([dev_index])
     s = engine.Scene()
     scenes.build(args.config, s)
     r.commit(s)
@@ -179,8 +186,9 @@ def main():
         std = r.render_params(p, o, strips=strips)
     dt_d2h = (time.perf_counter() - t1) / nd2h
 
-    tot = torch.tensor([float(my_rays), float(my_bytes[1])], dtype=torch.float64, device="cuda")
-    mx = torch.tensor([dt, stt.kernel_ms[1] / max(1, stt.frames), stt.kernel_ms[0] / max(1, stt.frames), dt_d2h], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if rehearsal else "cuda"
+    tot = torch.tensor([float(my_rays), float(my_bytes[1])], dtype=torch.float64, device=red_dev)
+    mx = torch.tensor([dt, stt.kernel_ms[1] / max(1, stt.frames), stt.kernel_ms[0] / max(1, stt.frames), dt_d2h], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -201,7 +209,7 @@ def main():
             "metric": "Mrays/sec at %dx%d %dspp" % (cfg.width, cfg.height, cfg.spp),
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
             "config": {"workload": cfg.name, "description": cfg.description, "width": cfg.width, "height": cfg.height, "spp": cfg.spp,
                        "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
                        "rays_per_step": int(rays_total)},

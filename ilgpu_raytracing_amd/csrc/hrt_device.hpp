@@ -841,15 +841,20 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         Res lastRes; bool haveRes = false;
         lastRes.L = lastRes.wi = mk3(0.f, 0.f, 0.f); lastRes.pdf = lastRes.w = lastRes.wSum = 0.f; lastRes.m = lastRes.lightId = 0;
 
-        for (int s = 0; s < spp; s++)
-        {
-            Rng rng = rng_for_sample(sb, (uint32_t)s);
-            bool wroteReservoir = false;        // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
-            F3 pos = gpos, nrm = gnrm, alb = galb, I = gI;
-            int shade = gshade; float ior = gior;
-            F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);
+        // Lanes do not wait for each other at sample boundaries: every lane runs its own (sample, depth)
+        // cursor through one flat bounce loop, so a lane whose path ended starts its next sample while its
+        // neighbours are still bouncing.  Per-pixel order is untouched (samples of a pixel stay sequential).
+        int s = 0, depth = 0;
+        Rng rng = rng_for_sample(sb, 0u);
+        bool wroteReservoir = false;            // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
+        F3 pos = gpos, nrm = gnrm, alb = galb, I = gI;
+        int shade = gshade; float ior = gior;
+        F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);
+        if (k.maxDepth <= 0) { for (; s < spp; s++) Lframe = Lframe + safe_color(Li); }
 
-            for (int depth = 0; depth < k.maxDepth; depth++)
+        while (s < spp)
+        {
+            bool ended = false;
             {
                 Ray ray;
                 bool terminated = false;
@@ -936,17 +941,35 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                         else T = T * (1.0f / maxC);
                     }
                 }
-                if (terminated) break;
-
-                // TraceNext :659-671 -- the one closest-hit site of the bounce loop
-                Hit h;
-                if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); break; }
-                pos = ray.o + ray.d * h.t;
-                nrm = normalize(h.n);
-                alb = h.albedo; shade = h.shade; ior = h.ior;
-                I = ray.d;
+                if (terminated) ended = true;
+                else
+                {   // TraceNext :659-671 -- the one closest-hit site of the bounce loop
+                    Hit h;
+                    if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); ended = true; }
+                    else
+                    {
+                        pos = ray.o + ray.d * h.t;
+                        nrm = normalize(h.n);
+                        alb = h.albedo; shade = h.shade; ior = h.ior;
+                        I = ray.d;
+                        depth++;
+                        if (depth >= k.maxDepth) ended = true;
+                    }
+                }
             }
-            Lframe = Lframe + safe_color(Li);
+            if (ended)
+            {
+                Lframe = Lframe + safe_color(Li);                  // :320
+                s++;
+                if (s < spp)
+                {   // next sample starts again from the G-buffer vertex (:212-231)
+                    rng = rng_for_sample(sb, (uint32_t)s);
+                    wroteReservoir = false;
+                    pos = gpos; nrm = gnrm; alb = galb; I = gI; shade = gshade; ior = gior;
+                    Li = mk3(0.f, 0.f, 0.f); T = mk3(1.f, 1.f, 1.f);
+                    depth = 0;
+                }
+            }
         }
         if (haveRes)
         {
