@@ -132,7 +132,16 @@ class RenderOpts(C.Structure):
 class DeviceViews(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("row_begin", "row_end", "strip_n", "strip_i", "width", "height", "device_id", "reserved")] + \
                [(n, C.c_void_p) for n in ("color", "depth", "objectId", "radiance", "gb_worldPos", "gb_normalWS",
-                                          "gb_baseColor", "gb_matId", "gb_objId", "gb_hitMask")]
+                                          "gb_baseColor", "gb_matId", "gb_objId", "gb_hitMask", "present_color")] + \
+               [("present_width", C.c_int32), ("present_height", C.c_int32)]
+
+
+class PresentParams(C.Structure):
+    _fields_ = [("out_width", C.c_int32), ("out_height", C.c_int32), ("mode", C.c_int32),
+                ("feedback", C.c_float), ("sharpness", C.c_float), ("clampK", C.c_float)]
+
+
+PRESENT_RESAMPLE, PRESENT_TAAU = 0, 1
 
 
 FLAG_COUNTERS = 1

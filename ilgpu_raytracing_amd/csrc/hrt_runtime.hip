@@ -15,6 +15,7 @@
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
 #include "hrt_wavefront.hpp"
+#include "hrt_post.hpp"
 #include "../../include/hip_raytrace.h"
 
 using namespace hrt;
@@ -160,6 +161,34 @@ hrt_wf_resolve_kernel(FrameK k, WfGeom g, DGBuffer gb, DFramebuffer fb, DReservo
     if (ord < g.nOrd) wf_resolve_pixel(k, g, gb, fb, resCur, W, ord);
 }
 
+// ---------------------------------------------------------------------------------------
+// Presentation kernels (hrt_post.hpp)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+hrt_taa_resolve_kernel(TaaK p)
+{
+    __shared__ float lut[256];                       // sRGB byte -> linear, same expression as UnpackSRGB
+    lut[threadIdx.x] = srgb_to_linear_byte((int)threadIdx.x);
+    __syncthreads();
+    const int total = p.outW * p.outH;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) taa_resolve_pixel(lut, p, idx);
+}
+
+__global__ void __launch_bounds__(256)
+hrt_blit_kernel(const int32_t* src, long long srcLen, int32_t* dst, long long dstLen)     // RTRenderer.cs:281-285
+{
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= dstLen || i >= srcLen) return;
+    dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256)
+hrt_bilinear_upsample_kernel(const int32_t* src, int srcW, int srcH, int32_t* dst, int dstW, int dstH)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < dstW * dstH) bilinear_upsample_pixel(src, srcW, srcH, dst, dstW, dstH, i);
+}
+
 // exactness probe: evaluates include/hrt_math.h on the device (tests compare with the oracle's bits)
 __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float* y, float* out)
 {
@@ -175,6 +204,7 @@ __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float
     case 13: { int v = hrt_f2i(a); r = __int_as_float(v); } break;
     case 14: r = 1.0f / a; break;    case 15: r = a / b; break;
     case 16: r = a * b + a; break;   // must NOT be contracted
+    case 17: r = hrt_log(a); break;  case 18: r = hrt_exp(a); break;  case 19: r = hrt_pow(a, b); break;
     }
     out[i] = r;
 }
@@ -198,6 +228,9 @@ struct DeviceState {
     DScene dscene{};
     void* packed[4] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri (device-private repack)
     DPacked dpacked{};
+    // presentation (TAAU history + display-size colour), device slot 0 only
+    int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
+    int present_w = 0, present_h = 0; bool taa_history_valid = false;
     // streamed path-trace workspace
     float* wf_mem = nullptr; size_t wf_bytes = 0;
     int* wf_cnt = nullptr; size_t wf_cnt_ints = 0;
@@ -301,6 +334,14 @@ int ensure_pixels(hrt_ctx* c, DeviceState& d, int64_t nPix)
     HIPCHK(c, alloc_res(d.resB, nPix, d.stream));
     d.nPix = nPix;
     return HRT_OK;
+}
+
+void free_present(DeviceState& d)
+{
+    if (d.present_color) (void)hipFree(d.present_color);
+    if (d.taa_hist_color) (void)hipFree(d.taa_hist_color);
+    if (d.taa_hist_obj) (void)hipFree(d.taa_hist_obj);
+    d.present_color = d.taa_hist_color = d.taa_hist_obj = nullptr; d.present_w = d.present_h = 0; d.taa_history_valid = false;
 }
 
 void free_workspace(DeviceState& d)
@@ -694,6 +735,7 @@ void hrt_destroy(hrt_ctx* c)
         free_pixels(d);
         free_scene(d);
         free_workspace(d);
+        free_present(d);
         if (d.counters) (void)hipFree(d.counters);
         for (int f = 0; f < DeviceState::kRing; f++)
             for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
@@ -812,6 +854,7 @@ int hrt_reset_history(hrt_ctx* c)
     if (rc != HRT_OK) return rc;
     for (DeviceState& d : c->dev)
     {
+        d.taa_history_valid = false;
         if (d.nPix == 0) continue;
         HIPCHK(c, hipSetDevice(d.device_id));
         DReservoir* rs[2] = {&d.resA, &d.resB};
@@ -950,6 +993,54 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     return hrt_synchronize(c, stats);
 }
 
+int hrt_present(hrt_ctx* c, const hrt_present_params* pp, int32_t* out_color_host)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!pp) return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: params is NULL");
+    if (pp->out_width <= 0 || pp->out_height <= 0 || (int64_t)pp->out_width * pp->out_height > 0x7FFFFFFFLL)
+        return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: output size must be positive");
+    if (pp->mode != HRT_PRESENT_RESAMPLE && pp->mode != HRT_PRESENT_TAAU) return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: unknown mode");
+    if (c->dev.size() != 1) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: presentation needs the whole frame on one device (single-device ctx)");
+    DeviceState& d = c->dev[0];
+    if (d.nPix == 0 || c->width <= 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: no frame rendered yet");
+    if (d.strip_n != 1 || d.row_begin != 0 || d.row_end != c->height) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: the last frame was a partial tile");
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
+    HIPCHK(c, hipSetDevice(d.device_id));
+    const int outW = pp->out_width, outH = pp->out_height, inW = c->width, inH = c->height;
+    const size_t outLen = (size_t)outW * outH;
+    if (d.present_w != outW || d.present_h != outH)
+    {   // RTTaa.Ensure (RTTaa.cs:34-47): new display size -> new history, invalid until written once
+        free_present(d);
+        HIPCHK(c, dalloc(d.present_color, (int64_t)outLen, d.stream));
+        HIPCHK(c, dalloc(d.taa_hist_color, (int64_t)outLen, d.stream));
+        HIPCHK(c, dalloc(d.taa_hist_obj, (int64_t)outLen, d.stream));
+        d.present_w = outW; d.present_h = outH; d.taa_history_valid = false;
+    }
+    const int blocks = (int)((outLen + 255) / 256);
+    if (pp->mode == HRT_PRESENT_TAAU)
+    {
+        TaaK k;
+        k.outColor = d.present_color; k.inColorLow = d.fb.color; k.inObjIdLow = d.fb.objectId;
+        k.historyColor = d.taa_hist_color; k.historyObjId = d.taa_hist_obj;
+        k.outW = outW; k.outH = outH; k.inW = inW; k.inH = inH;
+        k.feedback = pp->feedback > 0.f ? pp->feedback : 0.075f;           // tunables of RTTaa.cs:77-79
+        k.sharpness = pp->sharpness > 0.f ? pp->sharpness : 0.10f;
+        k.clampK = pp->clampK > 0.f ? pp->clampK : 1.25f;
+        k.isFirstFrame = d.taa_history_valid ? 0 : 1;
+        hipLaunchKernelGGL(hrt_taa_resolve_kernel, dim3(std::min(blocks, 256 * 16)), dim3(256), 0, d.stream, k);
+        d.taa_history_valid = true;
+    }
+    else if (inW == outW && inH == outH)
+        hipLaunchKernelGGL(hrt_blit_kernel, dim3(blocks), dim3(256), 0, d.stream, (const int32_t*)d.fb.color, (long long)d.nPix, d.present_color, (long long)outLen);
+    else
+        hipLaunchKernelGGL(hrt_bilinear_upsample_kernel, dim3(blocks), dim3(256), 0, d.stream, (const int32_t*)d.fb.color, inW, inH, d.present_color, outW, outH);
+    HIPCHK(c, hipGetLastError());
+    if (out_color_host) HIPCHK(c, hipMemcpyAsync(out_color_host, d.present_color, outLen * 4, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(c, hipStreamSynchronize(d.stream));
+    return HRT_OK;
+}
+
 int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
 {
     if (!c || !o) return HRT_ERR_INVALID_ARG;
@@ -961,6 +1052,7 @@ int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
     o->color = d.fb.color; o->depth = d.fb.depth; o->objectId = d.fb.objectId; o->radiance = d.fb.radiance;
     o->gb_worldPos = d.gb.worldPos; o->gb_normalWS = d.gb.normalWS; o->gb_baseColor = d.gb.baseColor;
     o->gb_matId = d.gb.matId; o->gb_objId = d.gb.objId; o->gb_hitMask = d.gb.hitMask;
+    o->present_color = d.present_color; o->present_width = d.present_w; o->present_height = d.present_h;
     return HRT_OK;
 }
 

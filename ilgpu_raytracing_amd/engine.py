@@ -52,6 +52,7 @@ def lib():
         L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
         L.hrt_synchronize.argtypes = [C.c_void_p, C.POINTER(T.Stats)]
+        L.hrt_present.argtypes = [C.c_void_p, C.POINTER(T.PresentParams), C.c_void_p]
         L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
         L.hrt_reset_history.argtypes = [C.c_void_p]
         L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -324,6 +325,23 @@ class RTRenderer:
         st = T.Stats()
         self._check(lib().hrt_synchronize(self._ctx, C.byref(st)))
         return st
+
+    def present(self, out_width, out_height, taau=True, out=None, feedback=0.0, sharpness=0.0, clamp_k=0.0):
+        """Presentation step of RenderDirectToPbo (RTRenderer.cs:208-231): TAAU resolve, or blit / bilinear upsample.
+        Returns the display-size packed colour as an int32 array."""
+        pp = T.PresentParams(out_width, out_height, T.PRESENT_TAAU if taau else T.PRESENT_RESAMPLE, feedback, sharpness, clamp_k)
+        if out is None:
+            out = np.zeros(out_width * out_height, np.int32)
+        self._check(lib().hrt_present(self._ctx, C.byref(pp), out.ctypes.data))
+        return out
+
+    def render_direct(self, out_width, out_height, frame, dt=0.0, render_scale=0.67, taau=True, flags=0):
+        """RenderDirectToPbo(pbo, width, height, frame, dt) end to end: internal size = round(out * renderScale)
+        (RTRenderer.cs:113-116), the two launches, then the presentation step.  Returns (display colour, Stats)."""
+        in_w = max(1, int(np.rint(np.float32(out_width) * np.float32(render_scale))))
+        in_h = max(1, int(np.rint(np.float32(out_height) * np.float32(render_scale))))
+        st = self.render_frame(in_w, in_h, frame, dt, None, flags)
+        return self.present(out_width, out_height, taau), st
 
     def reset_history(self):
         self._check(lib().hrt_reset_history(self._ctx))

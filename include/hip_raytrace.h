@@ -23,6 +23,8 @@
  *                          _cuda.Synchronize()                   RTRenderer.cs:233
  *                          Framebuffer.DownloadToCpu (the unused read-back hook)
  *                                                                Framebuffer.cs:148-160
+ *   hrt_present            pbo.MapCuda + RTTaa.ResolveUpsample | BlitKernel | BilinearUpsampleKernel
+ *                                                                RTRenderer.cs:208-231,281-345; RTTaa.cs:34-171
  *   hrt_synchronize        _cuda.Synchronize() when frames were enqueued without it  RTRenderer.cs:233
  *   hrt_device_buffers     GpuFramebuffer / GpuGBuffer views handed to the post kernels
  *                          (TAAU, blit) without leaving the device  RTRenderer.cs:155-161,208-231
@@ -127,7 +129,23 @@ typedef struct hrt_device_views {
     int32_t row_begin, row_end, strip_n, strip_i, width, height, device_id, reserved;
     void *color, *depth, *objectId, *radiance;
     void *gb_worldPos, *gb_normalWS, *gb_baseColor, *gb_matId, *gb_objId, *gb_hitMask;
+    void *present_color;                      /* display-size RGBA8 of the last hrt_present (NULL before) */
+    int32_t present_width, present_height;
 } hrt_device_views;
+
+/* Presentation step of RenderDirectToPbo after the two launches (RTRenderer.cs:208-231): the last frame
+ * rendered at (width,height) = (inW,inH) is resolved to the display size. */
+enum hrt_present_mode {
+    HRT_PRESENT_RESAMPLE = 0,   /* _enableTAAU == false: BlitKernel when sizes match, else BilinearUpsampleKernel
+                                   (RTRenderer.cs:225-231,281-345)                                              */
+    HRT_PRESENT_TAAU     = 1    /* RTTaa.ResolveUpsample (RTTaa.cs:49-171): history kept per display size,
+                                   first frame after (re)allocation or hrt_reset_history ignores it             */
+};
+typedef struct hrt_present_params {
+    int32_t out_width, out_height;
+    int32_t mode;                              /* hrt_present_mode */
+    float feedback, sharpness, clampK;         /* TAAU tunables; <= 0 selects the reference's 0.075 / 0.10 / 1.25 (RTTaa.cs:77-79) */
+} hrt_present_params;
 
 int  hrt_create(const int* device_ids, int n_dev, hrt_ctx** out);
 void hrt_destroy(hrt_ctx* ctx);
@@ -144,6 +162,10 @@ int  hrt_render_frame(hrt_ctx* ctx, const hrt_frame_params* params,
  * = per-launch HIP-event time summed over those frames (max over devices), frames = their
  * number.  A blocking hrt_render_frame is enqueue + hrt_synchronize. */
 int  hrt_synchronize(hrt_ctx* ctx, hrt_stats* stats);
+
+/* out_color_host: out_width*out_height packed 0xFFRRGGBB, may be NULL (result stays in hrt_device_views.present_color).
+ * Single-device contexts only; the last frame must have been a full-image render. */
+int  hrt_present(hrt_ctx* ctx, const hrt_present_params* params, int32_t* out_color_host);
 
 int  hrt_device_buffers(hrt_ctx* ctx, int dev, hrt_device_views* out);
 int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */

@@ -218,6 +218,50 @@ HRT_HD int hrt_f2i(float x)
     return (int)x;
 }
 
+/* ---- log / exp / pow (XMath.Pow in the TAAU sRGB conversions, RTTaa.cs:238-253) -------------
+ * pow(x, y) = exp(y * ln x) for x > 0, Cephes-style single-precision logf / expf.  Relative error
+ * ~|y ln x| * 1e-7: far below the 8-bit quantisation that follows every use on this path. */
+HRT_HD float hrt_log(float xin)
+{
+    if (!(xin > 0.0f)) return -1.0e30f;                       /* domain guard (never reached on the path) */
+    uint32_t u = hrt_f2u(xin);
+    int e = (int)((u >> 23) & 0xFFu) - 126;                   /* x = m * 2^e, m in [0.5, 1) */
+    if (((u >> 23) & 0xFFu) == 0u) {                          /* subnormal: scale into range first */
+        u = hrt_f2u(xin * 8388608.0f);
+        e = (int)((u >> 23) & 0xFFu) - 126 - 23;
+    }
+    float x = hrt_u2f((u & 0x007FFFFFu) | 0x3F000000u);
+    if (x < 0.707106781186547524f) { e = e - 1; x = x + x - 1.0f; }
+    else                           { x = x - 1.0f; }
+    float z = x * x;
+    float y = ((((((((7.0376836292E-2f * x - 1.1514610310E-1f) * x + 1.1676998740E-1f) * x - 1.2420140846E-1f) * x
+                   + 1.4249322787E-1f) * x - 1.6668057665E-1f) * x + 2.0000714765E-1f) * x - 2.4999993993E-1f) * x
+               + 3.3333331174E-1f) * x * z;
+    float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = x + y;
+    return z + 0.693359375f * fe;
+}
+HRT_HD float hrt_exp(float xin)
+{
+    if (xin > 88.0f) return 3.4028235e38f;
+    if (xin < -87.0f) return 0.0f;
+    float z = hrt_floor(1.44269504088896341f * xin + 0.5f);
+    float x = xin - z * 0.693359375f;
+    x = x - z * -2.12194440e-4f;
+    int n = hrt_f2i(z);
+    z = x * x;
+    z = (((((1.9875691500E-4f * x + 1.3981999507E-3f) * x + 8.3334519073E-3f) * x + 4.1665795894E-2f) * x
+          + 1.6666665459E-1f) * x + 5.0000001201E-1f) * z + x + 1.0f;
+    return z * hrt_u2f((uint32_t)(n + 127) << 23);            /* ldexp: |n| <= 127 by the range guards */
+}
+HRT_HD float hrt_pow(float x, float y)
+{
+    if (x == 0.0f) return (y > 0.0f) ? 0.0f : 1.0f;
+    return hrt_exp(y * hrt_log(x));
+}
+
 /* double.IsFinite(x) on a float (RTRay.cs:648-650), immune to any NaN folding */
 HRT_HD int hrt_isfinite(float x) { return (hrt_f2u(x) & 0x7F800000u) != 0x7F800000u; }
 

@@ -16,7 +16,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_api.cpp", "orc_kernels.hpp", "orc_scene.hpp")] + \
+    srcs = [os.path.join(_HERE, f) for f in ("orc_api.cpp", "orc_kernels.hpp", "orc_scene.hpp", "orc_post.hpp")] + \
            [os.path.join(_HERE, "..", "include", f) for f in ("hrt_types.h", "hrt_math.h", "hip_raytrace.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liborc.so"], stdout=subprocess.DEVNULL)
@@ -57,6 +57,8 @@ def lib():
         L.orc_math_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_dotnet_sort_by_key.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.POINTER(T.SceneDesc), C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 6
+        L.orc_present.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_float, C.c_float, C.c_float]
         _LIB = L
     return _LIB
 
@@ -66,7 +68,7 @@ def _fv(v):
 
 
 MATH_FN = {"sin": 0, "cos": 1, "tan": 2, "atan": 3, "atan2": 4, "acos": 5, "asin": 6, "rsqrt": 7, "sqrt": 8,
-           "fmin": 9, "fmax": 10, "floor": 11, "round": 12, "f2i": 13, "rcp": 14, "div": 15}
+           "fmin": 9, "fmax": 10, "floor": 11, "round": 12, "f2i": 13, "rcp": 14, "div": 15, "log": 17, "exp": 18, "pow": 19}
 
 
 def math_eval(name, x, y=None):
@@ -181,3 +183,18 @@ def trace_rays(scene_desc, origins, dirs, brute=False):
     lib().orc_trace_rays(C.byref(scene_desc), n, o.ctypes.data, d.ctypes.data, 1 if brute else 0,
                          t.ctypes.data, nrm.ctypes.data, alb.ctypes.data, obj.ctypes.data, shade.ctypes.data, hit.ctypes.data)
     return dict(t=t, normal=nrm, albedo=alb, objId=obj, shade=shade, hit=hit)
+
+
+def present(mode, low_color, low_objid, in_w, in_h, out_w, out_h, history=None, first_frame=True, feedback=0.075, sharpness=0.10, clamp_k=1.25):
+    """Oracle of the presentation step.  mode 0 = blit / bilinear upsample, 1 = TAAU (history = (color, objId) int32 arrays, updated in place)."""
+    out = np.zeros(out_w * out_h, np.int32)
+    lc = np.ascontiguousarray(low_color, dtype=np.int32)
+    lo = np.ascontiguousarray(low_objid, dtype=np.int32) if low_objid is not None else None
+    hc = history[0] if history is not None else None
+    ho = history[1] if history is not None else None
+    rc = lib().orc_present(mode, lc.ctypes.data, lo.ctypes.data if lo is not None else None, in_w, in_h, out.ctypes.data, out_w, out_h,
+                           hc.ctypes.data if hc is not None else None, ho.ctypes.data if ho is not None else None,
+                           1 if first_frame else 0, feedback, sharpness, clamp_k)
+    if rc != 0:
+        raise RuntimeError("orc_present failed")
+    return out

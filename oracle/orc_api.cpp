@@ -13,6 +13,7 @@
 #include <cstdio>
 #include "orc_kernels.hpp"
 #include "orc_scene.hpp"
+#include "orc_post.hpp"
 #include "../include/hip_raytrace.h"   // hrt_outputs layout only
 
 using namespace orc;
@@ -249,6 +250,7 @@ void orc_math_eval(int fn, int n, const float* x, const float* y, float* out)
         case 11: r = hrt_floor(a); break; case 12: r = hrt_round(a); break;
         case 13: { int v = hrt_f2i(a); std::memcpy(&r, &v, 4); } break;
         case 14: r = 1.0f / a; break;    case 15: r = a / b; break;
+        case 17: r = hrt_log(a); break;  case 18: r = hrt_exp(a); break;  case 19: r = hrt_pow(a, b); break;
         }
         out[i] = r;
     }
@@ -322,6 +324,29 @@ int orc_scene_load_mesh_instance(void* s_, const hrt_float3* pos, int nPos, cons
 }
 void orc_scene_rebuild_tlas(void* s) { static_cast<Scene*>(s)->RebuildTLAS(); }
 void orc_scene_get_desc(void* s, hrt_scene_desc* d) { static_cast<Scene*>(s)->GetDesc(*d); }
+
+// ------------------------------------------------------------------ presentation kernels
+// mode 0: RTRenderer's non-TAAU branch (blit when sizes match, bilinear upsample otherwise, RTRenderer.cs:225-231)
+// mode 1: RTTaa.ResolveUpsample (history arrays are read and written in place)
+int orc_present(int mode, const int32_t* lowColor, const int32_t* lowObjId, int inW, int inH, int32_t* outColor, int outW, int outH,
+                int32_t* historyColor, int32_t* historyObjId, int isFirstFrame, float feedback, float sharpness, float clampK)
+{
+    if (!lowColor || !outColor || inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0) return -1;
+    const int total = outW * outH;
+    if (mode == 1)
+    {
+        if (!lowObjId || !historyColor || !historyObjId) return -1;
+        TaaParams p;
+        p.outColor = outColor; p.inColorLow = lowColor; p.inObjIdLow = lowObjId; p.historyColor = historyColor; p.historyObjId = historyObjId;
+        p.outW = outW; p.outH = outH; p.inW = inW; p.inH = inH;
+        p.feedback = feedback; p.sharpness = sharpness; p.clampK = clampK; p.isFirstFrame = isFirstFrame;
+        p.motionScaleX = 0.f; p.motionScaleY = 0.f;
+        for (int i = 0; i < total; i++) RTTaa::TaaResolveKernel(i, p);
+    }
+    else if (inW == outW && inH == outH) { for (int i = 0; i < total; i++) RTPresent::BlitKernel(i, lowColor, (int64_t)inW * inH, outColor, total); }
+    else { for (int i = 0; i < total; i++) RTPresent::BilinearUpsampleKernel(i, lowColor, inW, inH, outColor, outW, outH); }
+    return 0;
+}
 
 int orc_hardware_threads(void) { unsigned n = std::thread::hardware_concurrency(); return n ? (int)n : 1; }
 
