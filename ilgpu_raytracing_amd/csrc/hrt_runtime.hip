@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "hrt_device.hpp"
@@ -616,7 +617,9 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     g.tilesX8 = (width + 7) / 8;
     g.nOrd = g.tilesX8 * d.n_strips * 64;
     const int spp = k.spp > 1 ? k.spp : 1;
-    long long sb = kWfMaxPaths / g.nOrd;
+    long long maxPaths = kWfMaxPaths;
+    if (const char* e = getenv("HRT_WF_MAX_PATHS")) { long long v = atoll(e); if (v > 0) maxPaths = v; }   // test knob: forces several sample batches
+    long long sb = maxPaths / g.nOrd;
     if (sb < 1) sb = 1;
     if (sb > spp) sb = spp;
     const long long batchPaths = sb * (long long)g.nOrd;

@@ -90,6 +90,20 @@ def test_frame_matches_oracle(orc, renderer, name, mode):
     assert gst.counters_valid == 1 and gst.n_devices == 1
 
 
+def test_streamed_sample_batches(orc, renderer, monkeypatch):
+    """spp larger than what fits the path workspace is processed in sample batches: Lframe is carried across
+    batches in sample order and resCur keeps the last writer.  HRT_WF_MAX_PATHS shrinks the workspace so that a
+    small frame needs 1-, 2- and 3-sample batches (7 spp -> 3 + 3 + 1 and 2 + 2 + 2 + 1)."""
+    builder, cfg, w, h, spp = scenes.build_textured_test_scene, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0)), 96, 64, 7
+    ref, ost, _ = H.oracle_frame(orc, builder, cfg, w, h, spp)
+    n_ord = ((w + 7) // 8) * ((h + 7) // 8) * 64
+    for per_batch in (3, 2, 1):
+        monkeypatch.setenv("HRT_WF_MAX_PATHS", str(n_ord * per_batch + 5))
+        got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, flags=T.FLAG_COUNTERS | T.FLAG_STREAMED)
+        H.assert_outputs_equal(ref, got)
+        assert gst.k[1].as_dict() == ost.k[1].as_dict()
+
+
 def test_counters_off_gives_same_pixels(renderer):
     builder, cfg, w, h, spp = CASES["config2_320x180"]
     a, sa, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, flags=T.FLAG_COUNTERS)
