@@ -529,32 +529,39 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     return "";
 }
 
+// copies the strips `owner` renders (rows [row_begin,row_end), strips s % strip_n == strip_i) of one per-pixel array
+// from src to dst (same global indexing on both sides) on `stream`: device -> host gather, or device -> device exchange
 template <class T>
-int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
+int copy_strips(hrt_ctx* c, const DeviceState& owner, T* dst, const T* src, int width, hipMemcpyKind kind, hipStream_t stream)
 {
-    if (!host || d.n_strips == 0) return HRT_OK;
+    if (!dst || owner.n_strips == 0) return HRT_OK;
     const size_t rowElems = (size_t)width;
-    if (d.strip_n == 1)
+    if (owner.strip_n == 1)
     {   // one contiguous row block
-        size_t off = (size_t)d.row_begin * rowElems;
-        size_t cnt = (size_t)(d.row_end - d.row_begin) * rowElems;
-        HIPCHK(c, hipMemcpyAsync(host + off, devp + off, cnt * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+        size_t off = (size_t)owner.row_begin * rowElems;
+        size_t cnt = (size_t)(owner.row_end - owner.row_begin) * rowElems;
+        HIPCHK(c, hipMemcpyAsync(dst + off, src + off, cnt * sizeof(T), kind, stream));
         return HRT_OK;
     }
     // interleaved 8-row strips: one strided 2-D copy for the full strips, one plain copy for a ragged last strip
-    int lastStrip = d.strip_i + (d.n_strips - 1) * d.strip_n;
-    int lastRows = std::min(8, (d.row_end - d.row_begin) - lastStrip * 8);
-    int fullStrips = lastRows == 8 ? d.n_strips : d.n_strips - 1;
-    size_t first = ((size_t)d.row_begin + (size_t)d.strip_i * 8) * rowElems;
+    int lastStrip = owner.strip_i + (owner.n_strips - 1) * owner.strip_n;
+    int lastRows = std::min(8, (owner.row_end - owner.row_begin) - lastStrip * 8);
+    int fullStrips = lastRows == 8 ? owner.n_strips : owner.n_strips - 1;
+    size_t first = ((size_t)owner.row_begin + (size_t)owner.strip_i * 8) * rowElems;
     if (fullStrips > 0)
-        HIPCHK(c, hipMemcpy2DAsync(host + first, (size_t)8 * rowElems * d.strip_n * sizeof(T), devp + first, (size_t)8 * rowElems * d.strip_n * sizeof(T),
-                                   (size_t)8 * rowElems * sizeof(T), (size_t)fullStrips, hipMemcpyDeviceToHost, d.stream));
+        HIPCHK(c, hipMemcpy2DAsync(dst + first, (size_t)8 * rowElems * owner.strip_n * sizeof(T), src + first, (size_t)8 * rowElems * owner.strip_n * sizeof(T),
+                                   (size_t)8 * rowElems * sizeof(T), (size_t)fullStrips, kind, stream));
     if (lastRows < 8 && lastRows > 0)
     {
-        size_t off = ((size_t)d.row_begin + (size_t)lastStrip * 8) * rowElems;
-        HIPCHK(c, hipMemcpyAsync(host + off, devp + off, (size_t)lastRows * rowElems * sizeof(T), hipMemcpyDeviceToHost, d.stream));
+        size_t off = ((size_t)owner.row_begin + (size_t)lastStrip * 8) * rowElems;
+        HIPCHK(c, hipMemcpyAsync(dst + off, src + off, (size_t)lastRows * rowElems * sizeof(T), kind, stream));
     }
     return HRT_OK;
+}
+template <class T>
+int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
+{
+    return copy_strips(c, d, host, devp, width, hipMemcpyDeviceToHost, d.stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -723,6 +730,14 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
             return fail(nullptr, HRT_ERR_HIP, m);
         }
     }
+    for (size_t i = 0; i < ids.size(); i++)
+        for (size_t j = 0; j < ids.size(); j++)
+            if (ids[i] != ids[j])
+            {   // tiles are exchanged device-to-device when ReSTIR reuse is on (xGMI peer copies)
+                (void)hipSetDevice(ids[i]);
+                hipError_t pe = hipDeviceEnablePeerAccess(ids[j], 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
     *out = c;
     return HRT_OK;
 }
@@ -891,8 +906,10 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     if (nosync && out) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: HRT_FLAG_NO_SYNC frames cannot gather to host (outputs must be NULL)");
     const bool reuse = (p->enableTemporalReuse != 0 || p->enableSpatialReuse != 0);
     const int nd = (int)c->dev.size();
-    if (reuse && (nd > 1 || sn > 1 || rb != 0 || re != p->height))
-        return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse across row tiles needs the G-buffer/reservoir exchange step (not built yet); render reuse frames on one full-image tile");
+    if (reuse && (sn > 1 || rb != 0 || re != p->height))
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse needs every pixel's G-buffer and previous reservoir: render reuse frames as full images "
+                    "(one ctx over several devices exchanges tiles itself; per-process tiles would need an inter-process exchange)");
+    if (reuse && nd > 1 && nosync) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: multi-device reuse frames cannot be enqueued with HRT_FLAG_NO_SYNC");
     const int64_t nPix = (int64_t)p->width * p->height;
     const bool count = (flags & HRT_FLAG_COUNTERS) != 0;
 
@@ -920,9 +937,10 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         d.n_strips = d.strip_i < S ? (S - d.strip_i + d.strip_n - 1) / d.strip_n : 0;
     }
 
-    for (DeviceState& d : c->dev)
-    {
-        HIPCHK(c, hipSetDevice(d.device_id));
+    // Framebuffer.GetReservoirPair: even frame -> prev = B, cur = A (Framebuffer.cs:132-145)
+    const bool even = (p->frame & 1) == 0;
+    const bool exchange = reuse && nd > 1;      // ReSTIR reuse reads other tiles' G-buffer and previous reservoirs
+    auto frame_k = [&](const DeviceState& d) {
         FrameK k;
         k.width = p->width; k.height = p->height; k.frame = p->frame;
         k.row_begin = d.row_begin; k.row_end = d.row_end; k.strip_n = d.strip_n; k.strip_i = d.strip_i;
@@ -931,52 +949,122 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         k.skyTop = p->skyTintTop; k.skyBottom = p->skyTintBottom;
         k.debugCamSeq = p->debugCamSeq; k.enableTemporal = p->enableTemporalReuse; k.enableSpatial = p->enableSpatialReuse;
         k.rngLockNoise = p->rngLockNoise; k.spp = p->spp; k.maxDepth = p->maxDepth;
-
+        return k;
+    };
+    auto tile_map = [&](const DeviceState& d) {
         TileMap tm;
         tm.tilesX = (p->width + 31) / 32;
         tm.tilesY = d.n_strips;
         tm.nTiles = tm.tilesX * tm.tilesY;
+        return tm;
+    };
+    // tracer variant: the smallest packed walker that covers the committed scene, or the reference layout
+    const bool usePacked = c->packed_ok && !(flags & HRT_FLAG_REFERENCE_LAYOUT);
+    const int variant = usePacked ? c->packed_feat : -1;
+    const bool mega = (flags & HRT_FLAG_MEGAKERNEL) ? true : ((flags & HRT_FLAG_STREAMED) ? false : c->small_scene);
+    auto with_tracer = [&](DeviceState& d, auto fn) -> int {
+        if (variant == 0)      { TracerPackedT<0> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }
+        else if (variant == 1) { TracerPackedT<1> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }
+        else if (variant == 3) { TracerPackedT<3> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }
+        TracerRef t; t.S = d.dscene; return fn(t);
+    };
+    // all-gather of per-pixel arrays between the devices of the ctx: every device receives the strips the others own.
+    // Copies run on the RECEIVER's stream after it has waited for the owner's event, so no host synchronisation is needed.
+    auto exchange_arrays = [&](int evIndex, auto get_arrays) -> int {
+        for (int j = 0; j < nd; j++)
+        {
+            DeviceState& dst = c->dev[j];
+            HIPCHK(c, hipSetDevice(dst.device_id));
+            for (int i = 0; i < nd; i++)
+            {
+                if (i == j) continue;
+                DeviceState& src = c->dev[i];
+                HIPCHK(c, hipStreamWaitEvent(dst.stream, src.ev[src.ring_head][evIndex], 0));
+                int rc = get_arrays(src, dst);
+                if (rc != HRT_OK) return rc;
+            }
+        }
+        return HRT_OK;
+    };
+    const int W = p->width;
+
+    // ---- phase 1: primary visibility on every device
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        const FrameK k = frame_k(d);
+        const TileMap tm = tile_map(d);
         if (count)
         {
             if (d.ring_head > 0 && !d.ring_counts) { int rc = hrt_synchronize(c, nullptr); if (rc != HRT_OK) return rc; HIPCHK(c, hipSetDevice(d.device_id)); }
             if (!d.ring_counts) HIPCHK(c, hipMemsetAsync(d.counters, 0, 20 * sizeof(unsigned long long), d.stream));
             d.ring_counts = true;
         }
-        // Framebuffer.GetReservoirPair: even frame -> prev = B, cur = A (Framebuffer.cs:132-145)
-        const bool even = (p->frame & 1) == 0;
-        DReservoir resPrev = even ? d.resB : d.resA;
-        DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
-
-        // tracer variant: the smallest packed walker that covers the committed scene, or the reference layout
-        const bool usePacked = c->packed_ok && !(flags & HRT_FLAG_REFERENCE_LAYOUT);
-        const int variant = usePacked ? c->packed_feat : -1;
-        const bool mega = (flags & HRT_FLAG_MEGAKERNEL) ? true : ((flags & HRT_FLAG_STREAMED) ? false : c->small_scene);
-        const bool doPrimary = tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY);
-        const dim3 grid(tm.nTiles), block(256);
-        auto run = [&](auto tr) -> int {
-            using TR = decltype(tr);
-            HIPCHK(c, hipEventRecord(ev[0], d.stream));
-            if (doPrimary)
-            {
+        HIPCHK(c, hipEventRecord(ev[0], d.stream));
+        if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
+        {
+            const dim3 grid(tm.nTiles), block(256);
+            int rcs = with_tracer(d, [&](auto tr) -> int {
+                using TR = decltype(tr);
                 if (count) hipLaunchKernelGGL((hrt_primary_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
                 else       hipLaunchKernelGGL((hrt_primary_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
                 HIPCHK(c, hipGetLastError());
-            }
-            HIPCHK(c, hipEventRecord(ev[1], d.stream));
+                return HRT_OK;
+            });
+            if (rcs != HRT_OK) return rcs;
+        }
+        HIPCHK(c, hipEventRecord(ev[1], d.stream));
+    }
+    if (exchange)
+    {   // SpatialCompatible reads objId / normalWS / worldPos of the CURRENT frame at other pixels (RTRay.cs:363-374)
+        int rc = exchange_arrays(1, [&](DeviceState& src, DeviceState& dst) -> int {
+            int r;
+            if ((r = copy_strips(c, src, dst.gb.worldPos, (const hrt_float3*)src.gb.worldPos, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, dst.gb.normalWS, (const hrt_float3*)src.gb.normalWS, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            return copy_strips(c, src, dst.gb.objId, (const int32_t*)src.gb.objId, W, hipMemcpyDeviceToDevice, dst.stream);
+        });
+        if (rc != HRT_OK) return rc;
+    }
+
+    // ---- phase 2: path trace + gather on every device
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        const FrameK k = frame_k(d);
+        const TileMap tm = tile_map(d);
+        DReservoir resPrev = even ? d.resB : d.resA;
+        DReservoir resCur = even ? d.resA : d.resB;
+        hipEvent_t* ev = d.ev[d.ring_head];
+        int rcs = with_tracer(d, [&](auto tr) -> int {
             return run_path_stage(c, d, tr, k, tm, p->width, resPrev, resCur, (long long)nPix, count, mega);
-        };
-        int rcs;
-        if (variant == 0)      { TracerPackedT<0> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
-        else if (variant == 1) { TracerPackedT<1> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
-        else if (variant == 3) { TracerPackedT<3> t; t.P = d.dpacked; t.S = d.dscene; rcs = run(t); }
-        else                   { TracerRef t; t.S = d.dscene; rcs = run(t); }
+        });
         if (rcs != HRT_OK) return rcs;
         HIPCHK(c, hipEventRecord(ev[2], d.stream));
-
+    }
+    if (exchange)
+    {   // next frame's resPrev must be complete on every device (temporal reprojection can land anywhere, RTRay.cs:339-360)
+        int rc = exchange_arrays(2, [&](DeviceState& src, DeviceState& dst) -> int {
+            const DReservoir& a = even ? src.resA : src.resB;
+            const DReservoir& b = even ? dst.resA : dst.resB;
+            int r;
+            if ((r = copy_strips(c, src, b.L, (const hrt_float3*)a.L, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, b.wi, (const hrt_float3*)a.wi, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, b.pdf, (const float*)a.pdf, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, b.w, (const float*)a.w, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, b.wSum, (const float*)a.wSum, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            if ((r = copy_strips(c, src, b.m, (const int32_t*)a.m, W, hipMemcpyDeviceToDevice, dst.stream)) != HRT_OK) return r;
+            return copy_strips(c, src, b.lightId, (const int32_t*)a.lightId, W, hipMemcpyDeviceToDevice, dst.stream);
+        });
+        if (rc != HRT_OK) return rc;
+    }
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        DReservoir resCur = even ? d.resA : d.resB;
+        hipEvent_t* ev = d.ev[d.ring_head];
         if (out)
         {   // per-tile gather into the caller's host framebuffer
-            const int W = p->width;
             int rc;
 #define G(hostp, devp) if ((rc = gather_rows(c, d, hostp, devp, W)) != HRT_OK) return rc
             G(out->color, d.fb.color); G(out->depth, d.fb.depth); G(out->objectId, d.fb.objectId);
@@ -1003,12 +1091,19 @@ int hrt_present(hrt_ctx* c, const hrt_present_params* pp, int32_t* out_color_hos
     if (pp->out_width <= 0 || pp->out_height <= 0 || (int64_t)pp->out_width * pp->out_height > 0x7FFFFFFFLL)
         return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: output size must be positive");
     if (pp->mode != HRT_PRESENT_RESAMPLE && pp->mode != HRT_PRESENT_TAAU) return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: unknown mode");
-    if (c->dev.size() != 1) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: presentation needs the whole frame on one device (single-device ctx)");
+    const int nd = (int)c->dev.size();
     DeviceState& d = c->dev[0];
     if (d.nPix == 0 || c->width <= 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: no frame rendered yet");
-    if (d.strip_n != 1 || d.row_begin != 0 || d.row_end != c->height) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: the last frame was a partial tile");
+    if (d.strip_n != nd || d.row_begin != 0 || d.row_end != c->height) return fail(c, HRT_ERR_INVALID_STATE, "hrt_present: the last frame was a partial tile");
     int rc = hrt_synchronize(c, nullptr);
     if (rc != HRT_OK) return rc;
+    HIPCHK(c, hipSetDevice(d.device_id));
+    for (int i = 1; i < nd; i++)
+    {   // the resolve runs on device slot 0: bring the other devices' strips of colour and objectId over
+        DeviceState& srcd = c->dev[i];
+        if ((rc = copy_strips(c, srcd, d.fb.color, (const int32_t*)srcd.fb.color, c->width, hipMemcpyDeviceToDevice, d.stream)) != HRT_OK) return rc;
+        if ((rc = copy_strips(c, srcd, d.fb.objectId, (const int32_t*)srcd.fb.objectId, c->width, hipMemcpyDeviceToDevice, d.stream)) != HRT_OK) return rc;
+    }
     HIPCHK(c, hipSetDevice(d.device_id));
     const int outW = pp->out_width, outH = pp->out_height, inW = c->width, inH = c->height;
     const size_t outLen = (size_t)outW * outH;

@@ -46,7 +46,9 @@
  * Multi-GPU: a ctx created on n devices splits the image into n contiguous row blocks
  * (scene replicated, no collective, per-tile hipMemcpyAsync gather into the caller's
  * host framebuffer).  One-process-per-GPU hosts instead create one ctx per process and
- * restrict it to a row range with hrt_render_opts.row_begin/row_end.
+ * restrict it to a row range / strip set with hrt_render_opts.  With ReSTIR reuse enabled a multi-device ctx
+ * exchanges G-buffer and reservoir tiles between its devices (device-to-device copies); partial tiles of a
+ * one-process-per-GPU host are refused while reuse is on.
  *
  * Status codes: 0 = ok, negative = error (message via hrt_last_error).
  */
