@@ -735,6 +735,9 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
     const float mixDelta = 1.f / 9.f;
     F3 n = fr.n;
     Res r; r.L = mk3(0.f, 0.f, 0.f); r.wi = mk3(0.f, 0.f, 0.f); r.pdf = 0.f; r.w = 0.f; r.wSum = 0.f; r.m = 0; r.lightId = 0;
+    // kept rolled: unrolled 8x the candidate body alone is ~3000 instructions (24 KB), a third of the instruction cache
+    // two CUs share; the loop-carried state is a handful of registers
+#pragma unroll 1
     for (int i = 0; i < 8; i++)
     {
         F3 wi = sample_hemisphere_cosine(fr, rng);
@@ -764,13 +767,14 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
         int rot = (int)(h & 3u);
         int rad = 1 + (int)((h >> 2) & 1u);
         int x0 = index % k.width, y0 = index / k.width;
-        // Neighbor8 (:377-391): offsets (-r,0)(r,0)(0,-r)(0,r)(-r,-r)(r,-r)(-r,r)(r,r) rotated by rot*90deg
-        const int bx[8] = {-1, 1, 0, 0, -1, 1, -1, 1};
-        const int by[8] = {0, 0, -1, 1, -1, -1, 1, 1};
-#pragma unroll
+        // Neighbor8 (:377-391): offsets (-r,0)(r,0)(0,-r)(0,r)(-r,-r)(r,-r)(-r,r)(r,r) rotated by rot*90deg.
+        // (bx+1) and (by+1) of neighbour j sit in nibble j of two constants, so the loop stays rolled.
+        const uint32_t kBX = 0x20201120u;     // bx+1 = 0,2,1,1,0,2,0,2
+        const uint32_t kBY = 0x22002011u;     // by+1 = 1,1,0,2,0,0,2,2
+#pragma unroll 1
         for (int j = 0; j < 8; j++)
         {
-            int ox = bx[j] * rad, oy = by[j] * rad;
+            int ox = ((int)((kBX >> (4 * j)) & 15u) - 1) * rad, oy = ((int)((kBY >> (4 * j)) & 15u) - 1) * rad;
             int dx = rot == 0 ? ox : (rot == 1 ? -oy : (rot == 2 ? -ox : oy));
             int dy = rot == 0 ? oy : (rot == 1 ? ox : (rot == 2 ? -oy : -ox));
             int nb = ((uint32_t)(x0 + dx) < (uint32_t)k.width && (uint32_t)(y0 + dy) < (uint32_t)k.height) ? (y0 + dy) * k.width + (x0 + dx) : -1;
@@ -822,7 +826,6 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     F3 Lframe = mk3(0.f, 0.f, 0.f);
 
     const int hitMask = gb.hitMask[index];
-    const F3 gpos = ld3(&gb.worldPos[index]);
 
     if (hitMask == 0)
     {
@@ -831,13 +834,19 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     }
     else
     {
-        const F3 gnrm = normalize(ld3(&gb.normalWS[index]));
-        const F3 galb = ld3(&gb.baseColor[index]);
-        const int packedMat = gb.matId[index];
-        const int gshade = packedMat & 0xFFFF;
-        const float gior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
-        const F3 gI = normalize(gpos - cv3(k.cam.origin));
         const SeedBase sb = seed_base((uint32_t)px, (uint32_t)py, k.frame, 0xC0FFEEu, k.rngLockNoise);
+        // The G-buffer vertex every sample starts from (:221-230) is re-read from memory at each sample start (an L2
+        // hit) instead of being held in 14 registers across the whole bounce loop.
+        F3 pos, nrm, alb, I; int shade; float ior;
+        auto start_vertex = [&]() {
+            pos = ld3(&gb.worldPos[index]);
+            nrm = normalize(ld3(&gb.normalWS[index]));
+            alb = ld3(&gb.baseColor[index]);
+            const int packedMat = gb.matId[index];
+            shade = packedMat & 0xFFFF;
+            ior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
+            I = normalize(pos - cv3(k.cam.origin));
+        };
         Res lastRes; bool haveRes = false;
         lastRes.L = lastRes.wi = mk3(0.f, 0.f, 0.f); lastRes.pdf = lastRes.w = lastRes.wSum = 0.f; lastRes.m = lastRes.lightId = 0;
 
@@ -847,8 +856,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         int s = 0, depth = 0;
         Rng rng = rng_for_sample(sb, 0u);
         bool wroteReservoir = false;            // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
-        F3 pos = gpos, nrm = gnrm, alb = galb, I = gI;
-        int shade = gshade; float ior = gior;
+        start_vertex();
         F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);
         if (k.maxDepth <= 0) { for (; s < spp; s++) Lframe = Lframe + safe_color(Li); }
 
@@ -965,7 +973,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 {   // next sample starts again from the G-buffer vertex (:212-231)
                     rng = rng_for_sample(sb, (uint32_t)s);
                     wroteReservoir = false;
-                    pos = gpos; nrm = gnrm; alb = galb; I = gI; shade = gshade; ior = gior;
+                    start_vertex();
                     Li = mk3(0.f, 0.f, 0.f); T = mk3(1.f, 1.f, 1.f);
                     depth = 0;
                 }
@@ -982,7 +990,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     F3 Lout = Lframe * (1.0f / (float)spp);
     if (fb.radiance) fb.radiance[index] = to3(Lout);
     fb.color[index] = pack_rgba8(Lout);
-    fb.depth[index] = cam_distance(k, gpos);
+    fb.depth[index] = cam_distance(k, ld3(&gb.worldPos[index]));
     fb.objectId[index] = gb.objId[index];
 }
 
