@@ -27,6 +27,17 @@ class MaterialRecord(C.Structure):
                 ("AlphaTexIndex", C.c_int32), ("TwoSided", C.c_int32), ("AlphaCutoff", C.c_float)]
 
 
+class MeshDesc(C.Structure):          # hrth_mesh_desc (include/hrt_host.h)
+    _fields_ = [("positions", C.c_void_p), ("n_positions", C.c_int), ("triangles", C.c_void_p), ("n_triangles", C.c_int),
+                ("texcoords", C.c_void_p), ("n_texcoords", C.c_int), ("tri_uvs", C.c_void_p),
+                ("tri_material_index", C.c_void_p), ("n_tri_material_index", C.c_int),
+                ("materials", C.POINTER(MaterialRecord)), ("n_materials", C.c_int),
+                ("tex_w", C.POINTER(C.c_int)), ("tex_h", C.POINTER(C.c_int)), ("tex_bgra", C.POINTER(C.c_uint8)), ("n_textures", C.c_int)]
+
+
+HRTH_ERR_ARGUMENT, HRTH_ERR_NOT_FOUND, HRTH_ERR_FORMAT = -1, -2, -3
+
+
 class Sphere(C.Structure):
     _fields_ = [("center", Float3), ("radius", C.c_float), ("albedo", Float3),
                 ("material", MaterialRecord), ("shading", C.c_int32), ("ior", C.c_float)]

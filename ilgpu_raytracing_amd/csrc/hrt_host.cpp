@@ -503,12 +503,16 @@ int hrth_scene_load_mesh_instance(void* s_, const hrt_float3* pos, int nPos, con
                                   const hrt_affine3x4* m)
 {
     HostScene* s = static_cast<HostScene*>(s_);
-    if (!s || !pos || !tris || !tex || !tuv || !mats || !m || nTris <= 0 || nPos <= 0 || nTex <= 0 || nMats <= 0) return -1;
+    if (!s || !pos || !tris || !tuv || !m || nTris <= 0 || nPos <= 0 || nTex < 0 || nMats < 0 || nTextures < 0) return -1;
+    if ((nTex > 0 && !tex) || (nMats > 0 && !mats) || (nTextures > 0 && (!texW || !texH || !texBGRA))) return -1;
+    // an OBJ without vt / usemtl statements refers to texcoord 0 / material 0 of lists that are empty: the reference
+    // uploads one zeroed element for an empty list (Scene.cs:370-377), so index 0 is the only one that stays valid
+    const int limTex = nTex > 0 ? nTex : 1, limMat = nMats > 0 ? nMats : 1;
     for (int i = 0; i < nTris; i++) {
         const hrt_mesh_tri& t = tris[i]; const hrt_mesh_tri_uv& u = tuv[i];
         if (t.i0 < 0 || t.i1 < 0 || t.i2 < 0 || t.i0 >= nPos || t.i1 >= nPos || t.i2 >= nPos) return -1;
-        if (u.t0 < 0 || u.t1 < 0 || u.t2 < 0 || u.t0 >= nTex || u.t1 >= nTex || u.t2 >= nTex) return -1;
-        if (triMat && i < nTriMat && (triMat[i] < 0 || triMat[i] >= nMats)) return -1;
+        if (u.t0 < 0 || u.t1 < 0 || u.t2 < 0 || u.t0 >= limTex || u.t1 >= limTex || u.t2 >= limTex) return -1;
+        if (triMat && i < nTriMat && (triMat[i] < 0 || triMat[i] >= limMat)) return -1;
     }
     return s->load_mesh_instance(pos, nPos, tris, nTris, tex, nTex, tuv, triMat, nTriMat, mats, nMats, texW, texH, texBGRA, nTextures, *m);
 }

@@ -426,13 +426,14 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     for (int64_t i = 0; i < nSP; i++) if (s->spherePrimIdx[i] < 0 || s->spherePrimIdx[i] >= nS) return "spherePrimIdx entry out of range";
     for (int64_t i = 0; i < nTP; i++) if (s->triPrimIdx[i] < 0 || s->triPrimIdx[i] >= nTri) return "triPrimIdx entry out of range";
     if (nTri > 0 && (nTM < nTri || nTU < nTri)) return "triMatIndex / meshTriUVs shorter than meshTris";
+    const int64_t limTC = nTC > 0 ? nTC : 1, limM = nM > 0 ? nM : 1;      // an empty list is one zeroed element (Scene.cs:370-377)
     for (int64_t i = 0; i < nTri; i++)
     {
         const hrt_mesh_tri& t = s->meshTris[i];
         if (t.i0 < 0 || t.i1 < 0 || t.i2 < 0 || t.i0 >= nPos || t.i1 >= nPos || t.i2 >= nPos) return "meshTris vertex index out of range";
         const hrt_mesh_tri_uv& u = s->meshTriUVs[i];
-        if (u.t0 < 0 || u.t1 < 0 || u.t2 < 0 || u.t0 >= nTC || u.t1 >= nTC || u.t2 >= nTC) return "meshTriUVs index out of range";
-        if (s->triMatIndex[i] < 0 || s->triMatIndex[i] >= nM) return "triMatIndex entry out of range";
+        if (u.t0 < 0 || u.t1 < 0 || u.t2 < 0 || u.t0 >= limTC || u.t1 >= limTC || u.t2 >= limTC) return "meshTriUVs index out of range";
+        if (s->triMatIndex[i] < 0 || s->triMatIndex[i] >= limM) return "triMatIndex entry out of range";
     }
     for (int64_t i = 0; i < nTxI; i++)
     {
@@ -515,7 +516,8 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         const hrt_mesh_tri& t = s->meshTris[ti];
         const hrt_float3 &a = s->meshPositions[t.i0], &b = s->meshPositions[t.i1], &c = s->meshPositions[t.i2];
         int mi = s->triMatIndex[ti];
-        const hrt_material& m = s->materials[mi];
+        static const hrt_material kZeroMaterial = {};
+        const hrt_material& m = nM > 0 ? s->materials[mi] : kZeroMaterial;
         bool dmap = m.HasDiffuseMap != 0 && m.DiffuseTexIndex >= 0 && m.DiffuseTexIndex < texLen;
         bool amap = m.HasAlphaMap != 0 && m.AlphaTexIndex >= 0 && m.AlphaTexIndex < texLen;
         bool rejects_opaque = 1.0f < m.AlphaCutoff;

@@ -69,6 +69,19 @@ def lib():
         L.hrth_scene_load_mesh_instance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
+        L.hrth_mesh_load_obj.argtypes = [C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+        L.hrth_mesh_get.argtypes = [C.c_void_p, C.POINTER(T.MeshDesc)]
+        L.hrth_mesh_free.argtypes = [C.c_void_p]
+        L.hrth_mesh_free.restype = None
+        L.hrth_mesh_material_name.argtypes = [C.c_void_p, C.c_int]
+        L.hrth_mesh_material_name.restype = C.c_char_p
+        L.hrth_mesh_texture_path.argtypes = [C.c_void_p, C.c_int]
+        L.hrth_mesh_texture_path.restype = C.c_char_p
+        L.hrth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]
+        L.hrth_image_free.argtypes = [C.POINTER(C.c_uint8)]
+        L.hrth_image_free.restype = None
+        L.hrth_scene_load_obj_instance.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(T.Affine3x4), C.c_float]
+        L.hrth_last_error.restype = C.c_char_p
         L.hrth_scene_rebuild_tlas.argtypes = [C.c_void_p]
         L.hrth_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrth_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
@@ -149,6 +162,65 @@ class MeshData:
                 self.tex_bytes.ctypes.data if self.n_tex else None, self.n_tex)
 
 
+class AssetFormatError(ValueError):
+    """FormatException / InvalidDataException / EndOfStreamException raised by the reference's loader."""
+
+
+def _raise_host(rc, what):
+    msg = (lib().hrth_last_error() or b"").decode("utf-8", "replace")
+    if rc == T.HRTH_ERR_NOT_FOUND:
+        raise FileNotFoundError(msg or what)
+    if rc == T.HRTH_ERR_FORMAT:
+        raise AssetFormatError(msg or what)
+    raise ValueError(msg or what)
+
+
+def load_obj(path, scale=1.0, flip_winding=True):
+    """MeshLoaderOBJ.Load (MeshLoaderOBJ.cs:67): OBJ + MTL + textures -> MeshData (material texture indices are local)."""
+    h = C.c_void_p()
+    rc = lib().hrth_mesh_load_obj(os.fsencode(path), scale, 1 if flip_winding else 0, C.byref(h))
+    if rc != 0:
+        _raise_host(rc, "load_obj failed")
+    try:
+        d = T.MeshDesc()
+        lib().hrth_mesh_get(h, C.byref(d))
+
+        def arr(ptr, n, dtype, width):
+            if n == 0:
+                return np.zeros((0, width), dtype)
+            return np.frombuffer(C.string_at(ptr, n * width * 4), dtype).reshape(n, width).copy()
+
+        mats = [T.MaterialRecord.from_buffer_copy(C.string_at(C.addressof(d.materials[i]), C.sizeof(T.MaterialRecord))) for i in range(d.n_materials)]
+        texs, off = [], 0
+        for i in range(d.n_textures):
+            w, hgt = d.tex_w[i], d.tex_h[i]
+            n = w * hgt * 4
+            texs.append(np.frombuffer(C.string_at(C.addressof(d.tex_bgra.contents) + off, n), np.uint8).reshape(hgt, w, 4).copy()
+                        if n else np.zeros((hgt, w, 4), np.uint8))
+            off += n
+        mesh = MeshData(arr(d.positions, d.n_positions, np.float32, 3), arr(d.triangles, d.n_triangles, np.int32, 3),
+                        arr(d.texcoords, d.n_texcoords, np.float32, 2), arr(d.tri_uvs, d.n_triangles, np.int32, 3), mats,
+                        arr(d.tri_material_index, d.n_tri_material_index, np.int32, 1).reshape(-1), texs)
+        mesh.material_names = [(lib().hrth_mesh_material_name(h, i) or b"").decode("utf-8", "replace") for i in range(d.n_materials)]
+        mesh.texture_paths = [(lib().hrth_mesh_texture_path(h, i) or b"").decode("utf-8", "replace") for i in range(d.n_textures)]
+        return mesh
+    finally:
+        lib().hrth_mesh_free(h)
+
+
+def load_image(path):
+    """LoadTextureBGRA (MeshLoaderOBJ.cs:456-593): .tga (raw / RLE, 8/24/32 bit) or uncompressed .bmp -> (H, W, 4) uint8 BGRA, row 0 = top."""
+    w, h, p = C.c_int(), C.c_int(), C.POINTER(C.c_uint8)()
+    rc = lib().hrth_image_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p))
+    if rc != 0:
+        _raise_host(rc, "load_image failed")
+    try:
+        n = w.value * h.value * 4
+        return np.frombuffer(C.string_at(p, n), np.uint8).reshape(h.value, w.value, 4).copy()
+    finally:
+        lib().hrth_image_free(p)
+
+
 # ------------------------------------------------------------------ Scene (Engine/Scene.cs, host lists + builders)
 class Scene:
     def __init__(self):
@@ -194,6 +266,14 @@ class Scene:
         r = lib().hrth_scene_load_mesh_instance(self._h, *mesh.ptrs(), C.byref(m))
         if r < 0:
             raise ValueError("load_mesh_instance: invalid mesh arrays")
+        return r
+
+    def load_obj_instance(self, obj_path, object_to_world=None, uniform_scale=1.0):
+        """Scene.LoadObjInstance(objPath, objectToWorld, uniformScale) (Scene.cs:144-256)."""
+        m = object_to_world if object_to_world is not None else T.identity_affine()
+        r = lib().hrth_scene_load_obj_instance(self._h, os.fsencode(obj_path), C.byref(m), uniform_scale)
+        if r < 0:
+            _raise_host(r, "load_obj_instance failed")
         return r
 
     def rebuild_tlas(self):

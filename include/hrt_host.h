@@ -14,6 +14,11 @@
  *   hrth_scene_load_mesh_instance      Scene.LoadObjInstance after MeshLoaderOBJ.Load
  *                                      (textures arrive as BGRA, as TextureSrc does)
  *                                                                     Scene.cs:151-256
+ *   hrth_mesh_load_obj / _get / _free  MeshLoaderOBJ.Load -> MeshHost (OBJ + MTL + textures)
+ *                                                                     MeshLoaderOBJ.cs:67-277,339-443
+ *   hrth_image_load / _free            LoadTextureBGRA (TGA raw/RLE; BMP) MeshLoaderOBJ.cs:456-593
+ *   hrth_scene_load_obj_instance       Scene.LoadObjInstance(objPath, objectToWorld, uniformScale)
+ *                                                                     Scene.cs:144-256
  *   hrth_scene_rebuild_tlas            Scene.RebuildTLAS              Scene.cs:358-368
  *   hrth_scene_get_desc                Scene.GetDeviceViews' 15 arrays (host side)
  *                                                                     Scene.cs:281-313
@@ -25,7 +30,10 @@
  *   hrth_sun_dir                       sun direction from (azimuth, elevation)
  *                                                                     RTRenderer.cs:174-178
  * Functions returning int give the new index (>= 0) or -1 on invalid arguments
- * (ArgumentException analogue).  Pointers returned through hrth_scene_get_desc stay
+ * (ArgumentException analogue).  The file loaders also return HRTH_ERR_NOT_FOUND
+ * (FileNotFoundException, Scene.cs:146-147) and HRTH_ERR_FORMAT (FormatException /
+ * InvalidDataException / EndOfStreamException raised while parsing); hrth_last_error() then
+ * holds the message (thread-local).  Pointers returned through hrth_scene_get_desc stay
  * valid until the next mutating call on that scene.
  */
 #ifndef HRT_HOST_H
@@ -34,6 +42,19 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+enum { HRTH_ERR_ARGUMENT = -1, HRTH_ERR_NOT_FOUND = -2, HRTH_ERR_FORMAT = -3 };
+
+/* MeshHost (MeshLoaderOBJ.cs:21-32) as borrowed arrays; textures are BGRA, 4 bytes per texel, concatenated in index order */
+typedef struct hrth_mesh_desc {
+    const hrt_float3* positions;       int n_positions;
+    const hrt_mesh_tri* triangles;     int n_triangles;
+    const hrt_float2* texcoords;       int n_texcoords;
+    const hrt_mesh_tri_uv* tri_uvs;                               /* n_triangles entries */
+    const int* tri_material_index;     int n_tri_material_index;
+    const hrt_material* materials;     int n_materials;
+    const int* tex_w; const int* tex_h; const uint8_t* tex_bgra; int n_textures;
+} hrth_mesh_desc;
 
 void* hrth_scene_new(void);
 void  hrth_scene_free(void* scene);
@@ -51,6 +72,15 @@ int   hrth_scene_load_mesh_instance(void* scene,
                                     const hrt_material* materials, int n_materials,
                                     const int* tex_w, const int* tex_h, const uint8_t* tex_bgra, int n_textures,
                                     const hrt_affine3x4* objectToWorld);
+int   hrth_mesh_load_obj(const char* path, float scale, int flipWinding, void** mesh_out);
+int   hrth_mesh_get(void* mesh, hrth_mesh_desc* out);
+const char* hrth_mesh_material_name(void* mesh, int material_index);
+const char* hrth_mesh_texture_path(void* mesh, int texture_index);
+void  hrth_mesh_free(void* mesh);
+int   hrth_image_load(const char* path, int* width, int* height, uint8_t** bgra_out);   /* release with hrth_image_free */
+void  hrth_image_free(uint8_t* bgra);
+int   hrth_scene_load_obj_instance(void* scene, const char* objPath, const hrt_affine3x4* objectToWorld, float uniformScale);
+const char* hrth_last_error(void);
 void  hrth_scene_rebuild_tlas(void* scene);
 void  hrth_scene_get_desc(void* scene, hrt_scene_desc* out);
 

@@ -1,0 +1,490 @@
+"""OBJ / MTL / TGA loader: product host code (hrt_assets.cpp through the C ABI of
+include/hrt_host.h) against the pure-Python restatement oracle/orc_assets.py of Engine/MeshLoaderOBJ.cs.
+Integer / byte data must match exactly; floats are decimal -> binary32 conversions and must match bit for bit.
+The reference holds no loader fixtures (parity unpinned, see oracle/orc_assets.py); files are synthetic."""
+import os
+
+import numpy as np
+import pytest
+
+from ilgpu_raytracing_amd import _types as T, engine, scenes
+from oracle import orc, orc_assets as OA
+from tests import asset_kit as K
+from tests.helpers import assert_outputs_equal, host_funcs
+
+MAT_FIELDS = ["HasDiffuseMap", "DiffuseTexIndex", "Shading", "IOR", "HasAlphaMap", "AlphaTexIndex", "TwoSided", "AlphaCutoff"]
+
+
+def f32_bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_mesh_equal(got, ref):
+    assert np.array_equal(f32_bits(got.positions), f32_bits(ref["positions"]))
+    assert np.array_equal(f32_bits(got.texcoords), f32_bits(ref["texcoords"]))
+    assert np.array_equal(got.triangles, ref["triangles"])
+    assert np.array_equal(got.tri_uvs, ref["tri_uvs"])
+    assert np.array_equal(got.tri_mat, ref["tri_material"])
+    assert got.material_names == ref["material_names"]
+    assert got.n_materials == len(ref["materials"])
+    for i, rm in enumerate(ref["materials"]):
+        gm = got.materials[i]
+        assert np.array_equal(f32_bits([gm.Kd.X, gm.Kd.Y, gm.Kd.Z]), f32_bits(rm["Kd"])), (i, "Kd")
+        for f in MAT_FIELDS:
+            a, b = getattr(gm, f), rm[f]
+            if isinstance(b, (np.floating, float)):
+                assert f32_bits([a])[0] == f32_bits([b])[0], (i, f)
+            else:
+                assert a == b, (i, f, a, b)
+    assert got.n_tex == len(ref["textures"])
+    off = 0
+    for i, t in enumerate(ref["textures"]):
+        assert (got.tex_h[i], got.tex_w[i]) == t.shape[:2]
+        n = t.size
+        assert np.array_equal(got.tex_bytes[off:off + n], t.reshape(-1)), "texture %d" % i
+        off += n
+    assert [os.path.normpath(p) for p in got.texture_paths] == [os.path.normpath(p) for p in ref["texture_paths"]]
+
+
+def both(path, scale=1.0, flip=True):
+    """Loads with both sides; they must agree on success or on failure."""
+    try:
+        ref = OA.load_obj(path, scale, flip)
+    except OA.FormatError:
+        with pytest.raises(engine.AssetFormatError):
+            engine.load_obj(path, scale, flip)
+        return None
+    got = engine.load_obj(path, scale, flip)
+    assert_mesh_equal(got, ref)
+    return got
+
+
+def write(path, text, newline="\n"):
+    with open(path, "wb") as f:
+        f.write(text.replace("\n", newline).encode("utf-8"))
+
+
+# ------------------------------------------------------------------------------------- number parsing
+HARD_FLOATS = [
+    "0.1", "-0.1", "+5", "-0", "0", ".5", "5.", "1E2", "1e+2", "1e-2", "1,234.5", "12,3", "007", "1e0000002",
+    "1.401298464324817e-45", "7.006492321624085e-46", "7.006492321624086e-46", "1e-45", "1e-46", "1.1754943508222875e-38",
+    "3.4028235e38", "3.4028235677973366e38", "3.40282356779733661637539395458142568448e38", "3.4028236e38", "1e39", "-1e400", "1e-400",
+    "1.000000059604644775390625", "1.00000005960464477539062500000001", "1.00000005960464477539062499999999",
+    "16777217", "16777219", "16777217.0000000001", "33554434", "33554435", "0.30000001192092896", "0.3000000268220901",
+    "9007199791611905", "123456789012345678901234567890", "0.000000000000000000000000000000000000011754942",
+    "Infinity", "-Infinity", "+infinity", "NaN", "nan", "-NaN",
+]
+BAD_FLOATS = ["abc", "1e", "1e+", "1.2.3", "--1", "0x10", ".", "+", "1f", "1d", ",1", "1 ,2", "e5", "1_000", "inf"]
+
+
+def test_decimal_to_float32_is_correctly_rounded(tmp_path):
+    rng = np.random.RandomState(7)
+    vals = list(HARD_FLOATS)
+    for _ in range(300):
+        nd = rng.randint(1, 22)
+        digits = "".join(str(d) for d in rng.randint(0, 10, nd))
+        point = rng.randint(0, nd + 1)
+        s = digits[:point] + "." + digits[point:]
+        if rng.rand() < 0.4:
+            s += "e%d" % rng.randint(-44, 39)
+        vals.append(("-" if rng.rand() < 0.3 else "") + s)
+    # float32 midpoints and their neighbours in decimal: the hard cases of rounding
+    for _ in range(100):
+        m = int(rng.randint(1 << 23, 1 << 24)) * 2 + 1          # odd 25-bit integer: a tie at 24 bits
+        e = int(rng.randint(-60, 40))
+        from fractions import Fraction
+        q = Fraction(m) * Fraction(2) ** e
+        num, den = q.numerator, q.denominator                   # den is a power of two: the decimal expansion is finite
+        k = 0
+        while den % 2 == 0:
+            den //= 2; k += 1
+        dec = str(num * 5 ** k)
+        dec = dec.rjust(k + 1, "0")
+        s = dec[:len(dec) - k] + "." + dec[len(dec) - k:] if k else dec
+        vals += [s, s + "0000000000001", s[:-1] + str(int(s[-1]) - 1) + "9999999999999" if s[-1] not in ".0" else s]
+    lines = ["v %s 0 1" % v for v in vals if " " not in v]
+    p = tmp_path / "nums.obj"
+    write(p, "\n".join(lines) + "\n")
+    ref = OA.load_obj(str(p), 1.0, True)
+    got = engine.load_obj(str(p), 1.0, True)
+    a, b = f32_bits(got.positions[:, 0]), f32_bits(ref["positions"][:, 0])
+    nan = np.isnan(got.positions[:, 0]) & np.isnan(ref["positions"][:, 0])
+    bad = np.nonzero((a != b) & ~nan)[0]
+    assert len(bad) == 0, [(lines[i], hex(a[i]), hex(b[i])) for i in bad[:5]]
+    # spot values with known answers
+    def one(s):
+        return OA.parse_float(s)
+    assert f32_bits([one("1.000000059604644775390625")])[0] == 0x3F800000          # tie -> even
+    assert f32_bits([one("1.00000005960464477539062500000001")])[0] == 0x3F800001   # double rounding would give ...000
+    assert f32_bits([one("7.006492321624085e-46")])[0] == 0x00000000
+    assert f32_bits([one("7.006492321624086e-46")])[0] == 0x00000001
+    assert f32_bits([one("3.4028235677973366e38")])[0] == 0x7F7FFFFF               # just below the overflow midpoint
+    assert f32_bits([one("3.40282356779733661637539395458142568448e38")])[0] == 0x7F800000   # the midpoint itself: tie -> even -> inf
+    assert f32_bits([one("16777217")])[0] == 0x4B800000
+
+
+@pytest.mark.parametrize("bad", BAD_FLOATS)
+def test_malformed_numbers_are_format_errors(tmp_path, bad):
+    p = tmp_path / "bad.obj"
+    write(p, "v 0 %s 1\n" % bad)
+    with pytest.raises(OA.FormatError):
+        OA.load_obj(str(p))
+    with pytest.raises(engine.AssetFormatError):
+        engine.load_obj(str(p))
+
+
+def test_scale_multiplies_in_binary32(tmp_path):
+    p = tmp_path / "s.obj"
+    write(p, "v 0.1 0.7 123.456\nv 1 2 3\nv -5.5 1e-3 9\nf 1 2 3\n")
+    got = both(str(p), scale=0.01, flip=False)
+    want = np.array([[0.1, 0.7, 123.456], [1, 2, 3], [-5.5, 1e-3, 9]], np.float32) * np.float32(0.01)
+    assert np.array_equal(f32_bits(got.positions), f32_bits(want))
+
+
+# ------------------------------------------------------------------------------------- OBJ statements
+def test_faces_fans_indices_and_winding(tmp_path):
+    text = """# comment
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 1.5 0
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 0 1
+f 1 2 3
+f 1/1 2/2 3/3 4/4 5/1
+f 1//1 2//1 3//1
+f 1/2/1 2/3/1 3/4/1
+f -5 -4 -3
+f -1/-1 -2/-2 -3/-3
+f 1 2
+f   1    2     3
+vp 1 2 3
+g group
+s off
+"""
+    p = tmp_path / "faces.obj"
+    write(p, text)
+    for flip in (False, True):
+        got = both(str(p), flip=flip)
+        assert len(got.triangles) == 1 + 3 + 1 + 1 + 1 + 1 + 0 + 1
+    got = both(str(p), flip=False)
+    assert got.triangles[1:4].tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]          # fan around the first vertex
+    assert got.tri_uvs[1:4].tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 0]]
+    assert got.tri_uvs[0].tolist() == [0, 0, 0] and got.tri_uvs[4].tolist() == [0, 0, 0]   # missing vt -> texcoord 0
+    assert got.tri_uvs[5].tolist() == [1, 2, 3]                                     # v/vt/vn
+    assert got.triangles[6].tolist() == [0, 1, 2] and got.triangles[7].tolist() == [4, 3, 2]   # negative = relative to the lists so far
+    assert got.tri_uvs[7].tolist() == [3, 2, 1]
+    assert both(str(p), flip=True).triangles[1].tolist() == [0, 2, 1]
+    assert got.n_materials == 0 and got.tri_mat.tolist() == [0] * 9                 # no usemtl: material index 0 of an empty list
+
+
+def test_line_endings_bom_and_column_zero_rule(tmp_path):
+    body = "v 0 0 0\nv 1 0 0\nv 0 1 0\n v 9 9 9\n\tv 8 8 8\nvt 0.25 0.75 0\n#v 7 7 7\nf 1/1 2/1 3/1\nfoo\nvx 1 2 3\n"
+    ref = None
+    for i, (nl, bom) in enumerate((("\n", b""), ("\r\n", b""), ("\r", b""), ("\n", b"\xef\xbb\xbf"))):
+        p = tmp_path / ("le%d.obj" % i)
+        with open(p, "wb") as f:
+            f.write(bom + body.replace("\n", nl).encode())
+        got = both(str(p))
+        assert len(got.positions) == 3 and len(got.triangles) == 1               # indented statements are not statements
+        if ref is not None:
+            assert np.array_equal(got.positions, ref.positions)
+        ref = got
+    p = tmp_path / "noeol.obj"
+    write(p, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3")                                # last line without a newline
+    assert len(both(str(p)).triangles) == 1
+
+
+@pytest.mark.parametrize("text", [
+    "v 1 2\nf 1 1 1\n",                 # too few coordinates -> float.Parse("")
+    "v 0 0 0\nf 1/ 1 1\n",              # empty vt after the slash -> int.Parse("")
+    "v 0 0 0\nf 1.5 1 1\n",
+    "v 0 0 0\nf a b c\n",
+    "v 0 0 0\nf 99999999999 1 1\n",     # Int32 overflow
+    "vt 0.5\n",
+    "v 1\t2 3\n",                        # a tab is not a separator: "1\\t2" is one token
+])
+def test_malformed_statements_fail_on_both_sides(tmp_path, text):
+    p = tmp_path / "m.obj"
+    write(p, text)
+    assert both(str(p)) is None
+
+
+def test_numbers_may_carry_surrounding_tabs(tmp_path):
+    p = tmp_path / "t.obj"
+    write(p, "v 1\t 2 \t3\nv 0 0 0\nv 1 1 1\nf 1\t 2 3\n")                         # "1\\t", "\\t3": white space around a number is allowed
+    got = both(str(p))
+    assert got.positions[0].tolist() == [1, 2, 3]
+
+
+def test_out_of_range_face_indices_load_but_cannot_enter_a_scene(tmp_path):
+    p = tmp_path / "oor.obj"
+    write(p, "v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7\nf 0 1 2\n")                      # index 0 -> count + 0 (MeshLoaderOBJ.cs:333)
+    got = both(str(p), flip=False)
+    assert got.triangles.tolist() == [[0, 1, 6], [3, 0, 1]]
+    s = engine.Scene()
+    with pytest.raises(engine.AssetFormatError):
+        s.load_obj_instance(str(p))
+
+
+# ------------------------------------------------------------------------------------- MTL statements, texture binding
+def _tri_obj(mtl_lines, uses=("a",), extra=""):
+    return "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\n" + "".join("usemtl %s\nf 1/1 2/1 3/1\n" % u for u in uses) + extra, "\n".join(mtl_lines) + "\n"
+
+
+def test_mtl_statements(tmp_path):
+    obj, mtl = _tri_obj([
+        "newmtl a", "Kd 0.25 0.5 0.75 0.9", "Ka 1 1 1", "Ns 10", "illum 2", "Ni 1.33 junk",
+        "newmtl b", "illum 3", "Ni 0",
+        "newmtl c", "illum 4", "Ni -2", "d 0.5",
+        "newmtl d", "illum 5", "Tr 0.25", "d 1.0",
+        "newmtl e", "illum 7", "Tr 0.0005",
+        "newmtl f", "illum 0", "d 0.9989999",
+        "newmtl g", "\tKd 0 0 0", " illum 7", "d 0.999",              # indented statements are ignored; 0.999f < 0.999f is false
+        "newmtl a2", "Kd 1e-3 +2 -0",
+        "newmtl   spaced name  ", "Kd 0 1 0",
+    ], uses=("b", "zz", "a", "spaced name", "b"))
+    write(tmp_path / "m.obj", obj)
+    write(tmp_path / "m.mtl", mtl)
+    got = both(str(tmp_path / "m.obj"))
+    assert got.material_names[:4] == ["b", "zz", "a", "spaced name"]              # order of first use, then MTL order for the rest
+    assert got.material_names[4:] == ["c", "d", "e", "f", "g", "a2"]
+    assert got.tri_mat.tolist() == [0, 1, 2, 3, 0]
+    by = dict(zip(got.material_names, got.materials))
+    assert [by[n].Shading for n in "abcdefg"] == [0, 1, 1, 2, 2, 0, 0]
+    assert [by[n].TwoSided for n in "abcdefg"] == [0, 0, 1, 1, 0, 1, 0]
+    assert by["b"].IOR == 1.0 and by["c"].IOR == 1.0 and abs(by["a"].IOR - 1.33) < 1e-6
+    assert (by["zz"].Kd.X, by["zz"].DiffuseTexIndex, by["zz"].AlphaCutoff) == (np.float32(0.8), -1, 0.5)   # usemtl of an undefined name
+
+
+def test_duplicate_newmtl_and_last_mtllib_wins(tmp_path):
+    write(tmp_path / "m.obj", "mtllib first.mtl\nmtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    write(tmp_path / "first.mtl", "newmtl a\nKd 1 0 0\nnewmtl only_in_first\n")
+    write(tmp_path / "m.mtl", "Kd 0.5 0.5 0.5\nmap_Kd orphan.tga\nnewmtl a\nKd 0 0 1\nnewmtl x\nKd 0 1 0\nnewmtl a\nKd 0 1 1\n")
+    got = both(str(tmp_path / "m.obj"))
+    assert got.material_names == ["a", "x"]                                        # redefinition keeps the slot, takes the last value
+    assert (got.materials[0].Kd.X, got.materials[0].Kd.Y, got.materials[0].Kd.Z) == (0.0, 1.0, 1.0)
+
+
+def test_missing_mtllib_file_is_not_an_error(tmp_path):
+    write(tmp_path / "m.obj", "mtllib nothere.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl q\nf 1 2 3\n")
+    got = both(str(tmp_path / "m.obj"))
+    assert got.material_names == ["q"] and got.n_tex == 0
+
+
+def test_texture_binding_dedupe_missing_and_backslashes(tmp_path):
+    os.makedirs(tmp_path / "tex")
+    K.write_tga(str(tmp_path / "tex" / "A.tga"), K.checker(8, 4, 2, (255, 0, 0), (0, 255, 0)), image_type=2, depth=24)
+    K.write_tga(str(tmp_path / "tex" / "mask.tga"), K.leaf_mask(8), image_type=10, depth=8)
+    obj, mtl = _tri_obj([
+        "newmtl a", "map_Kd tex/A.tga", "map_d tex\\mask.tga",
+        "newmtl b", "map_Kd tex/missing.tga", "map_d tex/A.tga",                   # missing diffuse: flag cleared; alpha reuses texture 0
+        "newmtl c", "map_Kd tex/A.TGA",                                            # same path up to case: not loaded again
+        "newmtl d", "map_Kd tex/first.tga", "map_Kd tex/mask.tga",                 # the later statement wins
+        "newmtl e", "map_d tex/gone.tga",
+        "newmtl f", "map_Kd " + str(tmp_path / "tex" / "A.tga"),                   # absolute path
+    ], uses=("a", "b", "c", "d", "e", "f"))
+    write(tmp_path / "m.obj", obj)
+    write(tmp_path / "m.mtl", mtl)
+    got = both(str(tmp_path / "m.obj"))
+    by = dict(zip(got.material_names, got.materials))
+    assert got.n_tex == 2
+    assert (by["a"].HasDiffuseMap, by["a"].DiffuseTexIndex, by["a"].HasAlphaMap, by["a"].AlphaTexIndex, by["a"].TwoSided) == (1, 0, 1, 1, 1)
+    assert (by["b"].HasDiffuseMap, by["b"].DiffuseTexIndex, by["b"].HasAlphaMap, by["b"].AlphaTexIndex) == (0, -1, 1, 0)
+    assert (by["d"].HasDiffuseMap, by["d"].DiffuseTexIndex) == (1, 1)
+    assert (by["e"].HasAlphaMap, by["e"].AlphaTexIndex, by["e"].TwoSided) == (0, -1, 1)   # TwoSided from the MTL statement stays
+    assert (by["f"].HasDiffuseMap, by["f"].DiffuseTexIndex) == (1, 0)
+    # on a case-sensitive file system "tex/A.TGA" does not exist: it is only found through the case-insensitive path table
+    assert (by["c"].HasDiffuseMap, by["c"].DiffuseTexIndex) == (1, 0)
+
+
+def test_unsupported_image_format_fails_loudly(tmp_path):
+    obj, mtl = _tri_obj(["newmtl a", "map_Kd pic.png"])
+    write(tmp_path / "m.obj", obj)
+    write(tmp_path / "m.mtl", mtl)
+    with open(tmp_path / "pic.png", "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+    with pytest.raises(engine.AssetFormatError, match="not supported"):
+        engine.load_obj(str(tmp_path / "m.obj"))
+
+
+# ------------------------------------------------------------------------------------- TGA / BMP
+@pytest.mark.parametrize("image_type", [2, 3, 10])
+@pytest.mark.parametrize("depth", [8, 24, 32])
+@pytest.mark.parametrize("top", [False, True])
+def test_tga_variants(tmp_path, image_type, depth, top):
+    rng = np.random.RandomState(depth + image_type)
+    img = rng.randint(0, 256, (7, 13, 4)).astype(np.uint8)
+    img[2:5, 3:11] = img[2, 3]                                                     # runs for the RLE writer, across row ends
+    img[5:7, :] = img[5, 0]
+    p = str(tmp_path / "t.tga")
+    K.write_tga(p, img, image_type=image_type, depth=depth, top_origin=top, id_bytes=b"id!" if top else b"")
+    got = engine.load_image(p)
+    ref = OA.load_tga(p)
+    assert np.array_equal(got, ref)
+    want = img.copy()
+    if depth == 24:
+        want[..., 3] = 255
+    if depth == 8:
+        want[..., 1] = want[..., 2] = want[..., 0]; want[..., 3] = 255
+    assert np.array_equal(got, want)                                               # row 0 = top whatever the file's origin bit
+
+
+def test_tga_errors(tmp_path):
+    img = K.checker(4, 4, 1, (1, 2, 3), (4, 5, 6))
+    cases = {"cmap": dict(color_map_type=1), "type1": dict(image_type=1, depth=8), "depth16": dict(depth=16), "trunc": dict(truncate=30),
+             "rle_trunc": dict(image_type=10, truncate=22)}
+    for name, kw in cases.items():
+        p = str(tmp_path / (name + ".tga"))
+        if name == "depth16":
+            K.write_tga(p, img, depth=24)
+            b = bytearray(open(p, "rb").read()); b[16] = 16
+            open(p, "wb").write(bytes(b))
+        else:
+            K.write_tga(p, img, **kw)
+        with pytest.raises(OA.FormatError):
+            OA.load_tga(p)
+        with pytest.raises(engine.AssetFormatError):
+            engine.load_image(p)
+    with pytest.raises(FileNotFoundError):
+        engine.load_image(str(tmp_path / "none.tga"))
+    p = str(tmp_path / "empty.tga")
+    K.write_tga(p, np.zeros((0, 0, 4), np.uint8))
+    assert engine.load_image(p).shape == (0, 0, 4) and OA.load_tga(p).shape == (0, 0, 4)
+
+
+def test_tga_rle_packet_overrunning_the_image_is_clipped(tmp_path):
+    import struct
+    p = str(tmp_path / "over.tga")
+    hdr = struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, 3, 2, 24, 0)
+    with open(p, "wb") as f:
+        f.write(hdr + bytes([0x80 | 9, 10, 20, 30]))                               # one run of 10 for a 6-pixel image (:566)
+    got = engine.load_image(p)
+    assert np.array_equal(got, OA.load_tga(p)) and got[..., :3].reshape(-1, 3).tolist() == [[10, 20, 30]] * 6
+
+
+@pytest.mark.parametrize("bits,bottom_up,alpha", [(24, True, False), (24, False, False), (32, True, False), (32, True, True)])
+def test_bmp_reader(tmp_path, bits, bottom_up, alpha):
+    rng = np.random.RandomState(bits)
+    img = rng.randint(0, 256, (5, 7, 4)).astype(np.uint8)
+    p = str(tmp_path / "t.bmp")
+    K.write_bmp(p, img, bits=bits, bottom_up=bottom_up, alpha_mask=alpha)
+    got = engine.load_image(p)
+    want = img.copy()
+    if not alpha:
+        want[..., 3] = 255
+    assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------- whole asset -> scene arrays
+def _orc_mesh(ref):
+    mats = []
+    for m in ref["materials"]:
+        r = T.MaterialRecord()
+        r.Kd.X, r.Kd.Y, r.Kd.Z = [float(v) for v in m["Kd"]]
+        for f in MAT_FIELDS:
+            setattr(r, f, m[f] if not isinstance(m[f], np.floating) else float(m[f]))
+        mats.append(r)
+    return engine.MeshData(ref["positions"], ref["triangles"], ref["texcoords"], ref["tri_uvs"], mats, ref["tri_material"], ref["textures"])
+
+
+def build_courtyard(b, obj_path, loader):
+    """Ground sphere + sun-lit courtyard mesh + a sphere instance; `loader(b, path, xform, scale)` adds the OBJ."""
+    g = b.add_sphere(scenes.sphere((0.0, -1000.0, 0.0), 999.9, (0.7, 0.7, 0.7)))
+    b.build_sphere_instance([g])
+    xf = T.identity_affine()
+    xf.m03, xf.m13, xf.m23 = 0.2, 0.1, -0.3
+    loader(b, obj_path, xf, 0.5)
+    s = b.add_sphere(scenes.sphere((0.9, 0.4, 1.2), 0.3, (0.9, 0.3, 0.2)))
+    b.build_sphere_instance([s])
+
+
+def _load_product(b, path, xf, scale):
+    b.load_obj_instance(path, xf, scale)
+
+
+def _load_oracle(b, path, xf, scale):
+    b.load_mesh_instance(_orc_mesh(OA.load_obj(path, scale, False)), xf)              # LoadObjInstance passes flipWinding: false (Scene.cs:149)
+
+
+def test_courtyard_mesh_and_scene_arrays(tmp_path):
+    obj = K.write_courtyard(str(tmp_path))
+    got = both(obj, scale=0.5, flip=False)
+    assert got.n_tex == 3 and got.material_names == ["floor", "foliage", "chrome", "crystal", "undefined_in_mtl", "never_used"]
+    assert len(got.triangles) == 3 + 2 * 10 * 10 + 3 * 12
+    sp, so = engine.Scene(), orc.OrcScene()
+    build_courtyard(sp, obj, _load_product)
+    build_courtyard(so, obj, _load_oracle)
+    a, b = sp.arrays(), so.arrays()
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
+    # flattening appends one copy per use: floor diffuse, foliage diffuse + alpha (Scene.cs:187-216)
+    assert len(a["texInfos"]) == 3 and len(a["materials"]) == 6
+
+
+def test_obj_without_vt_or_materials_enters_a_scene(tmp_path):
+    p = tmp_path / "bare.obj"
+    write(p, "v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv 0 1.5 0\nf 1 2 5\nf 2 3 5\nf 3 4 5\nf 4 1 5\nf 4 3 2 1\n")
+    sp, so = engine.Scene(), orc.OrcScene()
+    sp.load_obj_instance(str(p))
+    so.load_mesh_instance(_orc_mesh(OA.load_obj(str(p), 1.0, False)))
+    a, b = sp.arrays(), so.arrays()
+    for k in a:
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert len(a["materials"]) == 0 and len(a["meshTexcoords"]) == 0 and a["triMatIndex"].tolist() == [0] * 6
+
+
+def test_load_obj_instance_errors(tmp_path):
+    s = engine.Scene()
+    with pytest.raises(FileNotFoundError):
+        s.load_obj_instance(str(tmp_path / "nope.obj"))
+    with pytest.raises(ValueError):
+        s.load_obj_instance("")
+    p = tmp_path / "empty.obj"
+    write(p, "# nothing\nv 0 0 0\n")
+    with pytest.raises(engine.AssetFormatError):
+        s.load_obj_instance(str(p))
+    assert len(s.arrays()["instances"]) == 0                                       # a failed load leaves the scene untouched
+
+
+# ------------------------------------------------------------------------------------- render through the loaded asset
+COURT = scenes.Config("courtyard", 96, 64, 2, (0.4, 1.1, 3.2), (0.1, 0.5, 0.0), vfov=55.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reuse", [False, True])
+def test_courtyard_renders_bit_exact(tmp_path, renderer, reuse):
+    obj = K.write_courtyard(str(tmp_path))
+    cfg = COURT
+    w, h = cfg.width, cfg.height
+    sp, so = engine.Scene(), orc.OrcScene()
+    build_courtyard(sp, obj, _load_product)
+    build_courtyard(so, obj, _load_oracle)
+    r = renderer
+    r.commit(sp)
+    r.reset_history()
+    from tests.helpers import new_reservoirs
+    res = [new_reservoirs(w, h), new_reservoirs(w, h)]
+    for frame in range(3 if reuse else 1):
+        pg = scenes.frame_params(cfg, *host_funcs("hrt"), width=w, height=h, spp=cfg.spp, frame=frame, reuse=reuse)
+        po = scenes.frame_params(cfg, *host_funcs("orc", orc), width=w, height=h, spp=cfg.spp, frame=frame, reuse=reuse)
+        ga, go = T.alloc_outputs(w, h)
+        st = r.render_params(pg, go, flags=T.HRT_FLAG_COUNTERS)
+        oa, oo = T.alloc_outputs(w, h)
+        cur, prev = res[frame & 1], res[1 - (frame & 1)]
+        for k, a in cur.items():
+            oa[k] = a; setattr(oo, k, a.ctypes.data)
+        pv = T.Outputs()
+        for k, a in prev.items():
+            setattr(pv, k, a.ctypes.data)
+        so_st = orc.render_frame(so.desc(), po, oo, pv)
+        assert_outputs_equal(oa, ga)
+        assert st.k[0].as_dict() == so_st.k[0].as_dict() and st.k[1].as_dict() == so_st.k[1].as_dict()
+        assert st.k[1].tri_accepted > 0 and st.k[1].tri_tests > 0
+    hit = ga["gb_hitMask"].reshape(h, w)
+    assert 0.3 < hit.mean() <= 1.0
