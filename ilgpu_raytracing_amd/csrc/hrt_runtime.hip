@@ -103,6 +103,17 @@ hrt_wf_shade_kernel(FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long lo
     C.flush(counters);
 }
 
+#ifndef HRT_WALK_BLOCKS_PER_CU
+#define HRT_WALK_BLOCKS_PER_CU 8               // 8 workgroups x 4 waves = the 32 wave slots of a CU at <= 64 VGPRs
+#endif
+constexpr int kWalkBlocksPerCU = HRT_WALK_BLOCKS_PER_CU;
+// Walk launches either give every wave one path range (static) or let persistent waves pull ranges until none is
+// left (chained, RangeGrab).  Measured, path stage of configs 3 / 4 / 5: static 33.5 / 56.4 / 32.8 ms, chained
+// 36.2 / 37.2 / 21.7 ms: the triangle scenes gain 1.5x from full lanes, the sphere-instance scene is bound by L1
+// accesses (more live lanes do not help it) and loses the L1 sharing of four neighbouring ranges per workgroup.
+#ifndef HRT_CHAIN_FEAT0
+#define HRT_CHAIN_FEAT0 0
+#endif
 #ifndef HRT_WF_TRACE_WAVES
 #define HRT_WF_TRACE_WAVES 8
 #endif
@@ -129,21 +140,23 @@ hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigne
 // persistent-wave walk kernels (packed layout only) + the finish kernel that shades the winners
 template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
-hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
-    int range = wf_range(W.nRanges);
-    if (range >= 0) wf_walk_shadow_wave<FEAT, COUNT>(tr, W, vsel ? W.B : W.A, depth, range, C);
+    int own = -1;
+    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    wf_walk_shadow_wave<FEAT, COUNT>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
     C.flush(counters);
 }
 
 template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
-hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, unsigned long long* counters)
+hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
-    int range = wf_range(W.nRanges);
-    if (range >= 0) wf_walk_closest_wave<FEAT, COUNT>(tr, W, depth, range, C);
+    int own = -1;
+    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    wf_walk_closest_wave<FEAT, COUNT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
 
@@ -219,6 +232,7 @@ thread_local std::string g_create_error;
 
 struct DeviceState {
     int device_id = -1;
+    int n_cu = 256;                            // compute units (MI355X: 256)
     hipStream_t stream = nullptr;
     static constexpr int kRing = 128;          // frames that may be in flight between two syncs
     hipEvent_t ev[kRing][4] = {};
@@ -581,7 +595,7 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nR
 {
     const size_t planes = 2 * V_PLANES + R_PLANES + S_PLANES + 3 + G_PLANES;
     const size_t bytes = ((size_t)planes * (size_t)cap + 3 * (size_t)nOrd) * sizeof(float);
-    const size_t ints = (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
+    const size_t ints = (size_t)(2 * maxDepth + 2) * (size_t)nRanges + (size_t)maxDepth * 16;
     if (bytes > d.wf_bytes)
     {
         if (d.wf_mem) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.wf_mem); d.wf_mem = nullptr; d.wf_bytes = 0; }
@@ -601,6 +615,7 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nR
     W.A = take(V_PLANES, cap); W.B = take(V_PLANES, cap); W.R = take(R_PLANES, cap); W.SQ = take(S_PLANES, cap);
     W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap); W.accum = take(3, nOrd);
     W.cntA = d.wf_cnt; W.cntS = d.wf_cnt + (size_t)(maxDepth + 1) * (size_t)nRanges;
+    W.grab = d.wf_cnt + (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
     W.nRanges = nRanges;
     return HRT_OK;
 }
@@ -638,8 +653,11 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     int rc = ensure_workspace(c, d, cap, g.nOrd, nRanges, k.maxDepth, W);
     if (rc != HRT_OK) return rc;
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
+    // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
+    const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
     for (int b0 = 0; b0 < spp; b0 += (int)sb)
     {
+        HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
         g.batchStart = b0;
         g.batchCount = (int)std::min<long long>(sb, spp - b0);
         g.lastBatch = (b0 + g.batchCount >= spp) ? 1 : 0;
@@ -648,6 +666,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         for (int depth = 0; depth < k.maxDepth; depth++)
         {
             const int vsel = depth & 1;
+            const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0) ? 1 : 0;
             if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             if constexpr (PackedFeat<TR>::value >= 0)
@@ -655,14 +674,14 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 constexpr int F = PackedFeat<TR>::value;
                 if (count)
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), gridR, block, 0, d.stream, tr, W, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), gridR, block, 0, d.stream, tr, W, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
             }
@@ -721,6 +740,7 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
         DeviceState& d = c->dev[i];
         d.device_id = ids[i];
         hipError_t err = hipSetDevice(d.device_id);
+        if (err == hipSuccess) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d.device_id) == hipSuccess && cu > 0) d.n_cu = cu; }
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         for (int f = 0; f < DeviceState::kRing && err == hipSuccess; f++)
             for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[f][k]);

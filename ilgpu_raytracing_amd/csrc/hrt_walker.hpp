@@ -20,15 +20,35 @@
 namespace hrt {
 
 enum { M_IDLE = 0, M_TLAS = 1, M_TLEAF = 2, M_BLAS = 3, M_BLEAF = 4, M_DONE = 5 };
-constexpr int kRefillMin = 16;      // refill when at least this many lanes are idle (or none is active)
+#ifndef HRT_REFILL_MIN
+#define HRT_REFILL_MIN 16
+#endif
+constexpr int kRefillMin = HRT_REFILL_MIN;      // refill when at least this many lanes are idle (or none is active)
 constexpr int kNodeBurst = 6;       // max node steps per iteration while most lanes are still walking
+// Leaf phases run with few live lanes (a ray spends ~5-15 % of its steps on leaf entries), yet cost a full wave
+// instruction stream each time.  They are therefore gated: lanes standing on a leaf entry wait until enough of them
+// have gathered, or until too few lanes are left walking nodes to keep the wave busy.
+#ifndef HRT_GATE_T
+#define HRT_GATE_T 1
+#endif
+#ifndef HRT_GATE_B
+#define HRT_GATE_B 1
+#endif
+#ifndef HRT_WALK_LOW
+#define HRT_WALK_LOW 24
+#endif
+constexpr int kGateT = HRT_GATE_T, kGateB = HRT_GATE_B, kWalkLow = HRT_WALK_LOW;
 
 struct WalkResult { float t, tObj; int slot, prim; bool occluded; };
 
 // FEAT as in TracerPackedT.  ANY = shadow rays (any hit, tMax) vs closest hit.
-// fetch(i, ray, tMax) loads ray i of the queue (false: entry carries no ray); done(i, result) consumes its result.
-template <int FEAT, bool ANY, bool COUNT, class Fetch, class Done>
-HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done done, Cnt<COUNT>& C)
+// The queue is a chain of segments: nextSeg(base, n) (wave-uniform) hands out the next run of n entries starting at
+// global index base, or returns false when the chain is exhausted.  A wave keeps pulling segments while it has idle
+// lanes, so its lanes stay full until the whole chain has been handed out: a path range that holds only a few live
+// rays (every range does beyond the first bounce) no longer costs a wave of its own.
+// fetch(i, ray, tMax) loads entry i (false: entry carries no ray); done(i, result) consumes its result.
+template <int FEAT, bool ANY, bool COUNT, class NextSeg, class Fetch, class Done>
+HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
@@ -40,7 +60,8 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done do
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
-    int nextRay = 0;                 // wave-uniform: first unfetched ray
+    int segBase = 0, segN = 0, segCur = 0;      // wave-uniform: current segment and its first unfetched entry
+    bool more = true;                            // wave-uniform: the chain may still hold segments
     int mode = M_IDLE, rayIdx = -1;
     Ray w;                           // ray in use: world ray (TLAS modes) or object ray (BLAS modes; world ray parked in LDS)
     w.o = w.d = w.inv = mk3(0.f, 0.f, 0.f);
@@ -53,26 +74,36 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done do
 
     for (;;)
     {
-        // ---------------- refill idle lanes from the queue
+        // ---------------- refill idle lanes from the chain
         {
             unsigned long long idle = __ballot(mode == M_IDLE);
             int nIdle = __popcll(idle);
-            if (nextRay < n)
+            if (more && (nIdle >= kRefillMin || nIdle == 64))
             {
-                if (nIdle >= kRefillMin || nIdle == 64)
+                while (nIdle > 0)
                 {
-                    int my = nextRay + __popcll(idle & lt);
-                    if (mode == M_IDLE && my < n)
+                    if (segCur >= segN)
                     {
-                        rayIdx = my;
+                        more = nextSeg(segBase, segN);
+                        segCur = 0;
+                        if (!more) { segN = 0; break; }
+                        continue;
+                    }
+                    const int avail = segN - segCur;
+                    const int rank = __popcll(idle & lt);
+                    if (mode == M_IDLE && rank < avail)
+                    {
+                        rayIdx = segBase + segCur + rank;
                         bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false;
-                        if (fetch(my, w, tMaxW)) { C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS; }
+                        if (fetch(rayIdx, w, tMaxW)) { C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS; }
                         else mode = M_DONE;                   // queue entry without a ray (path already ended)
                     }
-                    nextRay += nIdle;
+                    segCur += nIdle < avail ? nIdle : avail;
+                    idle = __ballot(mode == M_IDLE);
+                    nIdle = __popcll(idle);
                 }
             }
-            else if (nIdle == 64) break;         // queue drained and every lane finished
+            if (!more && __popcll(__ballot(mode == M_IDLE)) == 64) break;         // chain drained and every lane finished
         }
 
         // ---------------- node steps: TLAS and BLAS nodes alike
@@ -115,7 +146,19 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done do
         }
 
         // ---------------- one TLAS leaf entry
-        if (mode == M_TLEAF)
+        bool runT = true, runB = true;
+        if (kGateT > 1 || kGateB > 1)
+        {
+            const int nWalkNow = __popcll(__ballot((mode == M_TLAS) || (kGeneral && mode == M_BLAS)));
+            const int nT = __popcll(__ballot(mode == M_TLEAF));
+            runT = nT >= kGateT || nWalkNow < kWalkLow;
+            if (kGeneral)
+            {
+                const int nB = __popcll(__ballot(mode == M_BLEAF));
+                runB = nB >= kGateB || nWalkNow < kWalkLow;
+            }
+        }
+        if (runT && mode == M_TLEAF)
         {
             FInst f = P.finst[li];
             C.inc(C_LEAF_INST);
@@ -151,7 +194,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, int n, Fetch fetch, Done do
         }
 
         // ---------------- one BLAS leaf entry
-        if (kGeneral && mode == M_BLEAF)
+        if (kGeneral && runB && mode == M_BLEAF)
         {
             const float lim = ANY ? tMaxW * iscale : tObj;
             if (iflags & FI_SPHERESET)

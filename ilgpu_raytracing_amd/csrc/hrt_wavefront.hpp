@@ -66,6 +66,7 @@ struct WfBuffers {
     Planes accum;                // 3 planes over pixel ordinals (Lframe carried across sample batches)
     int* cntA;                   // [depth][range] live paths of a range at a depth
     int* cntS;                   // [depth][range] shadow requests
+    int* grab;                   // [depth][2][8] range hand-out counters of the walk launches (zeroed per sample batch)
     int nRanges;
 };
 
@@ -346,40 +347,66 @@ HRT_D void wf_closest_wave(const TR& tr, const FrameK& k, const WfBuffers& W, co
 }
 
 // ------------------------------------------------------------------ persistent-wave variants (packed layout): walk, then finish
+// Hands the path ranges of one walk launch to persistent waves.  The ranges are cut into 8 contiguous partitions,
+// one per XCD (workgroup i runs on XCD i & 7), so waves that share an L2 walk neighbouring screen regions; a wave
+// whose partition is exhausted steals from the next ones.  One atomic per range per launch.
+struct RangeGrab {
+    int* ctr;            // 8 counters, zeroed before the launch
+    int nRanges;
+    int part, tried;     // wave-uniform
+    int own;             // >= 0: static mode, the wave takes this one range and nothing else
+    HRT_D void init(int* counters, int n, int ownRange) { ctr = counters; nRanges = n; part = blockIdx.x & 7; tried = 0; own = ownRange; }
+    HRT_D int next()
+    {
+        if (own != -1) { const int r = own < nRanges ? own : -1; own = nRanges; return r; }
+        int r = -1, t = tried;
+        if ((threadIdx.x & 63) == 0)
+        {
+            while (t < 8)
+            {
+                const int p = (part + t) & 7;
+                const int lo = (int)((long long)nRanges * p / 8), hi = (int)((long long)nRanges * (p + 1) / 8);
+                const int i = (hi > lo) ? atomicAdd(&ctr[p], 1) : 0;
+                if (i < hi - lo) { r = lo + i; break; }
+                t++;
+            }
+        }
+        tried = __builtin_amdgcn_readfirstlane(t);
+        return __builtin_amdgcn_readfirstlane(r);
+    }
+};
+
 template <int FEAT, bool COUNT>
-HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int range, Cnt<COUNT>& C)
+HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
-    const long long base = (long long)range * kRange;
-    const int n = W.cntS[depth * W.nRanges + range];
-    if (n == 0) return;
-    walk_queue<FEAT, true, COUNT>(tr, n,
-        [&](int j, Ray& r, float& tMax) { const long long q = base + j; r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d); tMax = 1e29f; return true; },
-        [&](int j, const WalkResult& res) {
+    RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
+    const int* cnt = W.cntS + (size_t)depth * W.nRanges;
+    walk_queue<FEAT, true, COUNT>(tr,
+        [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
+        [&](int q, Ray& r, float& tMax) { r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d); tMax = 1e29f; return true; },
+        [&](int q, const WalkResult& res) {
             if (!res.occluded)
             {
-                const long long q = base + j;
-                const long long slot = base + W.SQ.ldi(S_SLOT, q);
+                const long long slot = (long long)(q & ~(kRange - 1)) + W.SQ.ldi(S_SLOT, q);
                 V.st3(V_LI, slot, V.ld3(V_LI, slot) + W.SQ.ld3(S_ADD, q));
             }
         }, C);
 }
 
 template <int FEAT, bool COUNT>
-HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int range, Cnt<COUNT>& C)
+HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
-    const long long base = (long long)range * kRange;
-    const int n = W.cntA[depth * W.nRanges + range];
-    if (n == 0) return;
-    walk_queue<FEAT, false, COUNT>(tr, n,
-        [&](int i, Ray& r, float& tMax) {
-            const long long slot = base + i;
+    RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
+    const int* cnt = W.cntA + (size_t)depth * W.nRanges;
+    walk_queue<FEAT, false, COUNT>(tr,
+        [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
+        [&](int slot, Ray& r, float& tMax) {
             tMax = 1e30f;
             if (W.R.ldi(R_FLG, slot) & RF_DEAD) return false;
             r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = inv_dir(r.d);
             return true;
         },
-        [&](int i, const WalkResult& res) {
-            const long long slot = base + i;
+        [&](int slot, const WalkResult& res) {
             W.R.stf(R_HT, slot, res.t); W.R.sti(R_HSLOT, slot, res.slot); W.R.sti(R_HPRIM, slot, res.prim); W.R.stf(R_HTOBJ, slot, res.tObj);
         }, C);
 }

@@ -474,7 +474,7 @@ def test_courtyard_renders_bit_exact(tmp_path, renderer, reuse):
         pg = scenes.frame_params(cfg, *host_funcs("hrt"), width=w, height=h, spp=cfg.spp, frame=frame, reuse=reuse)
         po = scenes.frame_params(cfg, *host_funcs("orc", orc), width=w, height=h, spp=cfg.spp, frame=frame, reuse=reuse)
         ga, go = T.alloc_outputs(w, h)
-        st = r.render_params(pg, go, flags=T.HRT_FLAG_COUNTERS)
+        st = r.render_params(pg, go, flags=T.FLAG_COUNTERS)
         oa, oo = T.alloc_outputs(w, h)
         cur, prev = res[frame & 1], res[1 - (frame & 1)]
         for k, a in cur.items():

@@ -11,6 +11,7 @@ ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--ref", action="store_true", help="also time the reference-layout tracer")
 ap.add_argument("--spp", default="2:4,3:16,4:4,5:2")
 ap.add_argument("--check", action="store_true", help="compare packed vs reference-layout outputs")
+ap.add_argument("--modes", default="auto,stream,mega", help="subset of auto,stream,mega")
 args = ap.parse_args()
 spp = dict((int(a), int(b)) for a, b in (x.split(":") for x in args.spp.split(",")))
 r = engine.RTRenderer([0])
@@ -22,7 +23,7 @@ for cid in [int(c) for c in args.configs.split(",")]:
     st = r.render_params(p, None, flags=T.FLAG_COUNTERS)
     rays = sum(st.k[i].rays_closest + st.k[i].rays_shadow for i in range(2))
     line = "cfg%d %dx%d spp%d rays %.1fM build %.2fs upload %.2fs |" % (cid, p.width, p.height, p.spp, rays / 1e6, tb, tu)
-    modes = [("auto", 0), ("stream", T.FLAG_STREAMED), ("mega", T.FLAG_MEGAKERNEL)] + ([("mega+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL), ("stream+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_STREAMED)] if args.ref else [])
+    modes = [m for m in [("auto", 0), ("stream", T.FLAG_STREAMED), ("mega", T.FLAG_MEGAKERNEL)] if m[0] in args.modes.split(",")] + ([("mega+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_MEGAKERNEL), ("stream+reflayout", T.FLAG_REFERENCE_LAYOUT | T.FLAG_STREAMED)] if args.ref else [])
     for name, fl in modes:
         r.render_params(p, None, flags=fl)
         for _ in range(args.frames):
