@@ -466,23 +466,82 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     }
 
     // ---- repack
-    auto pack_nodes = [&](const hrt_bvh_node* src, int64_t n, std::vector<NodeQ>& dst) {
-        dst.resize((size_t)std::max<int64_t>(n, 1));
-        std::memset(dst.data(), 0, dst.size() * sizeof(NodeQ));
-        if (n == 0) { dst[0].lo.w = bits_f(kEnd); dst[0].hi.w = bits_f(kEnd); }    // the 1-element zero buffer: count 0, left 0 -> treat as end
-        for (int64_t i = 0; i < n; i++)
+    // Nodes are renumbered into walk order (depth-first, hit edge before skip edge): the child a ray enters after
+    // a hit is the next node in memory, so a descent reads consecutive 32-byte records (4 per 128-byte line)
+    // instead of jumping between the two halves of the builder's right-first numbering.  Pure permutation: every
+    // walk visits the same nodes in the same order.  perm[old - lo] = new - lo.
+    auto walk_order = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, int64_t root, std::vector<int32_t>& perm) {
+        const size_t n = (size_t)(hi - lo);
+        if (getenv("HRT_BUILDER_ORDER")) { perm.resize(n); for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i; return; }   // A/B knob
+        perm.assign(n, -1);
+        int32_t next = 0;
+        std::vector<int64_t> st;
+        st.push_back(root);
+        while (!st.empty())
+        {
+            const int64_t i = st.back(); st.pop_back();
+            if (i < lo || i >= hi || perm[(size_t)(i - lo)] >= 0) continue;
+            perm[(size_t)(i - lo)] = next++;
+            const hrt_bvh_node& b = src[i];
+            st.push_back(b.skipIndex);
+            if (b.count <= 0) st.push_back(b.left);
+        }
+        for (size_t i = 0; i < n; i++) if (perm[i] < 0) perm[i] = next++;        // unreachable nodes keep a slot
+    };
+    auto pack_range = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, const std::vector<int32_t>& perm, std::vector<NodeQ>& dst) {
+        auto remap = [&](int32_t link) -> int { return (link < lo || link >= hi) ? kEnd : (int)(lo + perm[(size_t)(link - lo)]); };
+        for (int64_t i = lo; i < hi; i++)
         {
             const hrt_bvh_node& b = src[i];
             int cnt = b.count > 0 ? b.count : 0;
-            if (cnt > 15 || n >= kEnd) out.ok = false;
-            int link = cnt > 0 ? b.first : (b.left & kEnd);
-            int hi = (b.skipIndex & kEnd) | (int)((unsigned)(cnt & 15) << 28);
-            dst[(size_t)i].lo = mkf4(b.boundsMin.X, b.boundsMin.Y, b.boundsMin.Z, bits_f(link));
-            dst[(size_t)i].hi = mkf4(b.boundsMax.X, b.boundsMax.Y, b.boundsMax.Z, bits_f(hi));
+            if (cnt > 15) out.ok = false;
+            int link = cnt > 0 ? b.first : remap(b.left);
+            int hiw = remap(b.skipIndex) | (int)((unsigned)(cnt & 15) << 28);
+            NodeQ& q = dst[(size_t)(lo + perm[(size_t)(i - lo)])];
+            q.lo = mkf4(b.boundsMin.X, b.boundsMin.Y, b.boundsMin.Z, bits_f(link));
+            q.hi = mkf4(b.boundsMax.X, b.boundsMax.Y, b.boundsMax.Z, bits_f(hiw));
         }
     };
-    pack_nodes(s->tlasNodes, nT, out.tlas);
-    pack_nodes(s->blasNodes, nB, out.blas);
+    auto alloc_nodes = [&](int64_t n, std::vector<NodeQ>& dst) {
+        dst.resize((size_t)std::max<int64_t>(n, 1));
+        std::memset(dst.data(), 0, dst.size() * sizeof(NodeQ));
+        if (n == 0) { dst[0].lo.w = bits_f(kEnd); dst[0].hi.w = bits_f(kEnd); }    // the 1-element zero buffer: count 0, left 0 -> treat as end
+        if (n >= kEnd) out.ok = false;
+    };
+    std::vector<int32_t> perm;
+    alloc_nodes(nT, out.tlas);
+    if (nT > 0) { walk_order(s->tlasNodes, 0, nT, 0, perm); pack_range(s->tlasNodes, 0, nT, perm, out.tlas); }
+    alloc_nodes(nB, out.blas);
+    {
+        // every instance owns the node range [blasRoot, blasRoot + blasNodeCount); each distinct range is renumbered
+        // on its own (root stays first).  Ranges that overlap without being equal cannot all be in walk order:
+        // the whole array then keeps the builder's numbering.
+        std::vector<std::pair<int64_t, int64_t>> ranges;
+        for (int64_t i = 0; i < nI; i++)
+            if (s->instances[i].blasNodeCount > 0) ranges.emplace_back((int64_t)s->instances[i].blasRoot, (int64_t)s->instances[i].blasRoot + s->instances[i].blasNodeCount);
+        std::sort(ranges.begin(), ranges.end());
+        ranges.erase(std::unique(ranges.begin(), ranges.end()), ranges.end());
+        bool disjoint = true;
+        for (size_t i = 1; i < ranges.size(); i++) if (ranges[i].first < ranges[i - 1].second) disjoint = false;
+        if (!disjoint)
+        {
+            perm.resize((size_t)nB);
+            for (size_t j = 0; j < perm.size(); j++) perm[j] = (int32_t)j;
+            pack_range(s->blasNodes, 0, nB, perm, out.blas);
+        }
+        else
+        {
+            int64_t at = 0;
+            for (const auto& r : ranges)
+            {
+                for (; at < r.first; at++) { perm.assign(1, 0); pack_range(s->blasNodes, at, at + 1, perm, out.blas); }   // owned by no instance: never walked
+                walk_order(s->blasNodes, r.first, r.second, r.first, perm);
+                pack_range(s->blasNodes, r.first, r.second, perm, out.blas);
+                at = r.second;
+            }
+            for (; at < nB; at++) { perm.assign(1, 0); pack_range(s->blasNodes, at, at + 1, perm, out.blas); }
+        }
+    }
     if (nT == 0)
     {   // reference semantics of the zeroed 1-element TLAS: node 0 has count 0, left 0 -> loops forever on a hit;
         // its bounds are all zero so only rays through the origin would.  We end the walk instead.
@@ -874,13 +933,28 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         // device-private repack (TracerPacked)
         const void* psrc[4] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data()};
         const size_t pbytes[4] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri)};
+#ifdef HRT_REPL
+        for (int i = 0; i < 4; i++)
+        {
+            const size_t padded = ((pbytes[i] + 4096 + 767) / 768) * 768;        // multiple of both record sizes
+            HIPCHK(c, hipMalloc(&d.packed[i], padded * HRT_REPL));
+            for (int r = 0; r < HRT_REPL; r++)
+                HIPCHK(c, hipMemcpyAsync((char*)d.packed[i] + padded * r, psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
+        }
+        d.dpacked.stride[0] = (long long)((((pbytes[0] + 4096 + 767) / 768) * 768) / sizeof(NodeQ));
+        d.dpacked.stride[1] = (long long)((((pbytes[1] + 4096 + 767) / 768) * 768) / sizeof(FInst));
+        d.dpacked.stride[2] = (long long)((((pbytes[2] + 4096 + 767) / 768) * 768) / sizeof(NodeQ));
+        d.dpacked.stride[3] = (long long)((((pbytes[3] + 4096 + 767) / 768) * 768) / sizeof(FTri));
+#else
         for (int i = 0; i < 4; i++)
         {
             HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
         }
+#endif
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
+        d.dpacked.nTlas = (int)ph.tlas.size();
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;
@@ -1196,3 +1270,15 @@ int hrt_math_probe(hrt_ctx* c, int fn, int n, const float* x, const float* y, fl
 }
 
 } // extern "C"
+
+#ifdef HRT_WALK_STATS
+// variant builds only (tools/walk_stats.py): read and clear the walker's phase statistics of the current device
+extern "C" int hrt_debug_walk_stats(unsigned long long* out48)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(hrt::g_walk_stats), sizeof(unsigned long long) * 48) != hipSuccess) return -1;
+    unsigned long long z[48] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hrt::g_walk_stats), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -37,9 +37,24 @@ constexpr int kNodeBurst = 6;       // max node steps per iteration while most l
 #ifndef HRT_WALK_LOW
 #define HRT_WALK_LOW 24
 #endif
+#ifndef HRT_LOOKAHEAD
+#define HRT_LOOKAHEAD 1
+#endif
 constexpr int kGateT = HRT_GATE_T, kGateB = HRT_GATE_B, kWalkLow = HRT_WALK_LOW;
 
 struct WalkResult { float t, tObj; int slot, prim; bool occluded; };
+
+// Tuning aid (variant build -DHRT_WALK_STATS, tools/walk_stats.py): how often each phase of the loop runs and with how
+// many live lanes.  [0] iterations [1] node steps [2] lanes in node steps [3] TLEAF runs [4] lanes [5] BLEAF runs
+// [6] lanes [7] retire runs [8] lanes [9] idle lanes summed over iterations [10] segments pulled [11] waves
+#ifdef HRT_WALK_STATS
+__device__ unsigned long long g_walk_stats[2][24];
+#define WSTAT(i, v) ws[i] += (unsigned long long)(v)
+#define WTIME(i) { const long long wnow_ = (long long)__builtin_readcyclecounter(); ws[i] += (unsigned long long)(wnow_ - wt_); wt_ = wnow_; }
+#else
+#define WSTAT(i, v)
+#define WTIME(i)
+#endif
 
 // FEAT as in TracerPackedT.  ANY = shadow rays (any hit, tMax) vs closest hit.
 // The queue is a chain of segments: nextSeg(base, n) (wave-uniform) hands out the next run of n entries starting at
@@ -54,12 +69,21 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
     constexpr bool kAlpha = (FEAT & 2) != 0;
     __shared__ float park_mem[kGeneral ? 9 : 1][256];
     RayPark park; park.sh = park_mem;
+#ifdef HRT_REPL
+    DPacked P = tr.P;
+    { const int cp = (int)((blockIdx.x >> 3) % HRT_REPL); P.tlas += cp * P.stride[0]; P.finst += cp * P.stride[1]; P.blas += cp * P.stride[2]; P.ftri += cp * P.stride[3]; }
+#else
     const DPacked& P = tr.P;
+#endif
     const DScene& S = tr.S;
     Tex tex(S);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
 
+#ifdef HRT_WALK_STATS
+    unsigned long long ws[20] = {};     // [12..16] shader-clock cycles in refill / node steps / TLEAF / BLEAF / retire
+    long long wt_ = (long long)__builtin_readcyclecounter();
+#endif
     int segBase = 0, segN = 0, segCur = 0;      // wave-uniform: current segment and its first unfetched entry
     bool more = true;                            // wave-uniform: the chain may still hold segments
     int mode = M_IDLE, rayIdx = -1;
@@ -78,6 +102,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
         {
             unsigned long long idle = __ballot(mode == M_IDLE);
             int nIdle = __popcll(idle);
+            WSTAT(0, 1); WSTAT(9, nIdle);
             if (more && (nIdle >= kRefillMin || nIdle == 64))
             {
                 while (nIdle > 0)
@@ -86,6 +111,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     {
                         more = nextSeg(segBase, segN);
                         segCur = 0;
+                        WSTAT(10, 1);
                         if (!more) { segN = 0; break; }
                         continue;
                     }
@@ -106,29 +132,56 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             if (!more && __popcll(__ballot(mode == M_IDLE)) == 64) break;         // chain drained and every lane finished
         }
 
+        WTIME(12);
         // ---------------- node steps: TLAS and BLAS nodes alike
         for (int burst = 0; burst < kNodeBurst; burst++)
         {
             const bool walking = (mode == M_TLAS) || (kGeneral && mode == M_BLAS);
             const int nWalk = __popcll(__ballot(walking));
             if (nWalk == 0 || (burst > 0 && nWalk < 24)) break;
+            WSTAT(1, 1); WSTAT(2, nWalk);
             if (walking)
             {
                 const bool top = !kGeneral || mode == M_TLAS;
                 const NodeQ* nodes = top ? P.tlas : P.blas;
+                // In walk order the node entered after a hit on an inner node is the next record, usually in the same
+                // 128-byte line: it is fetched together with the node itself, so a hit costs no second memory round trip
+                // (the walk is bound by the latency of dependent loads, not by their number).
+                const int last = (top ? P.nTlas : blasEnd) - 1;
                 NodeQ nd = nodes[cur];
-                C.inc(C_NODE_VISITS);
+#if HRT_LOOKAHEAD
+                NodeQ nd1 = nodes[cur < last ? cur + 1 : cur];
+#endif
+#ifdef HRT_EXTRA_LOAD      // experiment: one more 16-byte load per node visit (is the walk bound by L1 accesses?)
+                { const float4* q = &nodes[cur].hi; asm volatile("" : "+v"(q)); float4 x = *q; nd.hi.x = __builtin_fminf(nd.hi.x, x.x); }
+#endif
                 const float lim = top ? (ANY ? tMaxW : bestT) : (ANY ? tMaxW * iscale : tObj);
-                int sk = wbits(nd.hi);
-                const int cnt = (int)((unsigned)sk >> 28);
-                sk &= kEnd;
-                if (!hit_box(w, nd.lo, nd.hi, 0.001f, lim)) cur = sk;
-                else if (cnt > 0)
+                for (int k = 0; k < (HRT_LOOKAHEAD ? 2 : 1); k++)
                 {
-                    if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
-                    else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
+                    C.inc(C_NODE_VISITS);
+                    int sk = wbits(nd.hi);
+                    const int cnt = (int)((unsigned)sk >> 28);
+                    sk &= kEnd;
+                    bool again = false;
+                    if (!hit_box(w, nd.lo, nd.hi, 0.001f, lim)) cur = sk;
+                    else if (cnt > 0)
+                    {
+                        if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
+                        else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
+                    }
+                    else
+                    {
+                        const int link = wbits(nd.lo) & kEnd;
+                        again = (k == 0) && HRT_LOOKAHEAD && link == cur + 1 && cur < last;
+                        cur = link;
+                    }
+#if HRT_LOOKAHEAD
+                    if (!again) break;
+                    nd = nd1;
+#else
+                    (void)again;
+#endif
                 }
-                else cur = wbits(nd.lo) & kEnd;
             }
             // walk ends
             if (kGeneral && mode == M_BLAS && !(cur < blasEnd))
@@ -145,6 +198,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             if (mode == M_TLAS && cur == kEnd) mode = M_DONE;
         }
 
+        WTIME(13);
         // ---------------- one TLAS leaf entry
         bool runT = true, runB = true;
         if (kGateT > 1 || kGateB > 1)
@@ -158,6 +212,10 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                 runB = nB >= kGateB || nWalkNow < kWalkLow;
             }
         }
+#ifdef HRT_WALK_STATS
+        { const int a = __popcll(__ballot(runT && mode == M_TLEAF)); if (a) { WSTAT(3, 1); WSTAT(4, a); }
+          const int b = __popcll(__ballot(kGeneral && runB && mode == M_BLEAF)); if (b) { WSTAT(5, 1); WSTAT(6, b); } }
+#endif
         if (runT && mode == M_TLEAF)
         {
             FInst f = P.finst[li];
@@ -193,6 +251,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             if (mode == M_TLEAF && li == lend) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
         }
 
+        WTIME(14);
         // ---------------- one BLAS leaf entry
         if (kGeneral && runB && mode == M_BLEAF)
         {
@@ -282,14 +341,23 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             }
         }
 
+        WTIME(15);
         // ---------------- retire finished rays
+#ifdef HRT_WALK_STATS
+        { const int a = __popcll(__ballot(mode == M_DONE)); if (a) { WSTAT(7, 1); WSTAT(8, a); } }
+#endif
         if (mode == M_DONE)
         {
             WalkResult r; r.t = bestT; r.tObj = bestTObj; r.slot = bestSlot; r.prim = bestPrim; r.occluded = occl;
             done(rayIdx, r);
             mode = M_IDLE;
         }
+        WTIME(16);
     }
+#ifdef HRT_WALK_STATS
+    ws[11] = 1;
+    if (lane == 0) for (int i = 0; i < 17; i++) atomicAdd(&g_walk_stats[ANY ? 0 : 1][i], ws[i]);
+#endif
 }
 
 } // namespace hrt

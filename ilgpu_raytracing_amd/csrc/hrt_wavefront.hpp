@@ -47,15 +47,23 @@ struct Planes {                              // plane p of slot i = base[p * str
     HRT_D void sti(int p, long long i, int v) const { base[p * stride + i] = __int_as_float(v); }
     HRT_D F3 ld3(int p, long long i) const { return mk3(ldf(p, i), ldf(p + 1, i), ldf(p + 2, i)); }
     HRT_D void st3(int p, long long i, F3 v) const { stf(p, i, v.x); stf(p + 1, i, v.y); stf(p + 2, i, v.z); }
+    // A group of 4 planes starting at plane p can instead hold one 16-byte record per slot (record i at float 4*i of the
+    // group): what a walker lane fetches for ONE ray at a time is then one dwordx4 load from one page instead of four
+    // dword loads from four planes (strides are multiples of 256 floats, so records stay 16-byte aligned).
+    HRT_D float4 ld4(int p, long long i) const { return *reinterpret_cast<const float4*>(base + p * stride + 4 * i); }
+    HRT_D void st4(int p, long long i, float4 v) const { *reinterpret_cast<float4*>(base + p * stride + 4 * i) = v; }
 };
+HRT_D float4 mkq(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
 // vertex state (buffers A / B, ping-pong per bounce)
 enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG = 18, V_PID = 19, V_MAT = 20, V_IOR = 21, V_PLANES = 22 };
 // ray request written by wf_shade for the same slot
-enum { R_O = 0, R_D = 3, R_T = 6, R_RNG = 9, R_FLG = 10, R_HT = 11, R_HSLOT = 12, R_HPRIM = 13, R_HTOBJ = 14, R_PLANES = 15 };   // R_H*: raw winner of the closest-hit walk
+// RQ_A = (o.xyz, d.x)  RQ_B = (d.yz, flags, rng)  RQ_H = raw winner of the closest-hit walk (t, tObj, leaf slot, primitive): 16-byte records
+enum { RQ_A = 0, RQ_B = 4, R_T = 8, RQ_H = 11, R_PLANES = 15 };
 enum { RF_DEAD = 1, RF_WROTE = 2 };          // R_FLG / V_MAT(bit 16+) flags
 // shadow request (compacted per range)
-enum { S_O = 0, S_D = 3, S_ADD = 6, S_SLOT = 9, S_PLANES = 10 };
+// SQ_A = (o.xyz, d.x)  SQ_B = (d.yz, slot in range, add.x): 16-byte records; add.yz in two planes
+enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_PLANES = 10 };
 // reservoir staging per path id
 enum { G_L = 0, G_WI = 3, G_PDF = 6, G_W = 7, G_WSUM = 8, G_M = 9, G_LID = 10, G_FLAG = 11, G_PLANES = 12 };
 
@@ -254,15 +262,18 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
                     else T = T * (1.0f / maxC);
                 }
             }
-            W.R.st3(R_O, slot, ray.o); W.R.st3(R_D, slot, ray.d); W.R.st3(R_T, slot, T);
-            W.R.sti(R_RNG, slot, (int)rng.s); W.R.sti(R_FLG, slot, flg);
+            W.R.st4(RQ_A, slot, mkq(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
+            W.R.st4(RQ_B, slot, mkq(ray.d.y, ray.d.z, __int_as_float(flg), __int_as_float((int)rng.s)));
+            W.R.st3(R_T, slot, T);
         }
         int total;
         int off = wave_prefix(wantShadow, total);
         if (wantShadow)
         {
             long long q = base + sqCount + off;
-            W.SQ.st3(S_O, q, so); W.SQ.st3(S_D, q, sd); W.SQ.st3(S_ADD, q, sadd); W.SQ.sti(S_SLOT, q, (int)(slot - base));
+            W.SQ.st4(SQ_A, q, mkq(so.x, so.y, so.z, sd.x));
+            W.SQ.st4(SQ_B, q, mkq(sd.y, sd.z, __int_as_float((int)(slot - base)), sadd.x));
+            W.SQ.stf(S_ADDY, q, sadd.y); W.SQ.stf(S_ADDZ, q, sadd.z);
         }
         sqCount += total;
     }
@@ -282,11 +293,12 @@ HRT_D void wf_shadow_wave(const TR& tr, const WfBuffers& W, const Planes& V, int
         if (j < n)
         {
             const long long q = base + j;
-            Ray r; r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d);
+            const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
+            Ray r; r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
             if (!tr.template occluded<COUNT>(r, 1e29f, C))
             {
-                const long long slot = base + W.SQ.ldi(S_SLOT, q);
-                V.st3(V_LI, slot, V.ld3(V_LI, slot) + W.SQ.ld3(S_ADD, q));
+                const long long slot = base + __float_as_int(qb.z);
+                V.st3(V_LI, slot, V.ld3(V_LI, slot) + mk3(qb.w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q)));
             }
         }
     }
@@ -310,10 +322,11 @@ HRT_D void wf_closest_wave(const TR& tr, const FrameK& k, const WfBuffers& W, co
         Hit h; Ray r;
         if (i < n)
         {
-            dead = (W.R.ldi(R_FLG, slot) & RF_DEAD) != 0;        // Russian roulette ended the path in wf_shade
+            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
+            dead = (__float_as_int(qb.z) & RF_DEAD) != 0;        // Russian roulette ended the path in wf_shade
             if (!dead)
             {
-                r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = inv_dir(r.d);
+                r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
                 if (!tr.template closest<COUNT>(r, h, C)) missed = true;
                 else survive = !lastDepth;
             }
@@ -336,9 +349,10 @@ HRT_D void wf_closest_wave(const TR& tr, const FrameK& k, const WfBuffers& W, co
             Vn.st3(V_IDIR, o, r.d);
             Vn.st3(V_T, o, W.R.ld3(R_T, slot));
             Vn.st3(V_LI, o, V.ld3(V_LI, slot));
-            Vn.sti(V_RNG, o, W.R.ldi(R_RNG, slot));
+            const float4 qb2 = W.R.ld4(RQ_B, slot);
+            Vn.sti(V_RNG, o, __float_as_int(qb2.w));
             Vn.sti(V_PID, o, V.ldi(V_PID, slot));
-            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((W.R.ldi(R_FLG, slot) & RF_WROTE) << 16));
+            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((__float_as_int(qb2.z) & RF_WROTE) << 16));
             Vn.stf(V_IOR, o, h.ior);
         }
         outCount += total;
@@ -383,12 +397,16 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W
     const int* cnt = W.cntS + (size_t)depth * W.nRanges;
     walk_queue<FEAT, true, COUNT>(tr,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
-        [&](int q, Ray& r, float& tMax) { r.o = W.SQ.ld3(S_O, q); r.d = W.SQ.ld3(S_D, q); r.inv = inv_dir(r.d); tMax = 1e29f; return true; },
+        [&](int q, Ray& r, float& tMax) {
+            const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
+            r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d); tMax = 1e29f; return true;
+        },
         [&](int q, const WalkResult& res) {
             if (!res.occluded)
             {
-                const long long slot = (long long)(q & ~(kRange - 1)) + W.SQ.ldi(S_SLOT, q);
-                V.st3(V_LI, slot, V.ld3(V_LI, slot) + W.SQ.ld3(S_ADD, q));
+                const float4 qb = W.SQ.ld4(SQ_B, q);
+                const long long slot = (long long)(q & ~(kRange - 1)) + __float_as_int(qb.z);
+                V.st3(V_LI, slot, V.ld3(V_LI, slot) + mk3(qb.w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q)));
             }
         }, C);
 }
@@ -402,12 +420,13 @@ HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& 
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int slot, Ray& r, float& tMax) {
             tMax = 1e30f;
-            if (W.R.ldi(R_FLG, slot) & RF_DEAD) return false;
-            r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = inv_dir(r.d);
+            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
+            if (__float_as_int(qb.z) & RF_DEAD) return false;
+            r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
             return true;
         },
         [&](int slot, const WalkResult& res) {
-            W.R.stf(R_HT, slot, res.t); W.R.sti(R_HSLOT, slot, res.slot); W.R.sti(R_HPRIM, slot, res.prim); W.R.stf(R_HTOBJ, slot, res.tObj);
+            W.R.st4(RQ_H, slot, mkq(res.t, res.tObj, __int_as_float(res.slot), __int_as_float(res.prim)));
         }, C);
 }
 
@@ -428,17 +447,19 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
         Hit h; Ray r;
         if (i < n)
         {
-            const bool dead = (W.R.ldi(R_FLG, slot) & RF_DEAD) != 0;
+            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
+            const bool dead = (__float_as_int(qb.z) & RF_DEAD) != 0;
             bool missed = false;
             if (!dead)
             {
-                r.o = W.R.ld3(R_O, slot); r.d = W.R.ld3(R_D, slot); r.inv = mk3(0.f, 0.f, 0.f);
-                const float ht = W.R.ldf(R_HT, slot);
+                r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = mk3(0.f, 0.f, 0.f);
+                const float4 qh = W.R.ld4(RQ_H, slot);
+                const float ht = qh.x;
                 if (!(ht < 1e29f)) missed = true;
                 else if (!lastDepth)
                 {
                     survive = true;
-                    tr.finish_hit(r, ht, W.R.ldf(R_HTOBJ, slot), W.R.ldi(R_HSLOT, slot), W.R.ldi(R_HPRIM, slot), h);
+                    tr.finish_hit(r, ht, qh.y, __float_as_int(qh.z), __float_as_int(qh.w), h);
                 }
             }
             if (!survive)
@@ -460,9 +481,10 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
             Vn.st3(V_IDIR, o, r.d);
             Vn.st3(V_T, o, W.R.ld3(R_T, slot));
             Vn.st3(V_LI, o, V.ld3(V_LI, slot));
-            Vn.sti(V_RNG, o, W.R.ldi(R_RNG, slot));
+            const float4 qb2 = W.R.ld4(RQ_B, slot);
+            Vn.sti(V_RNG, o, __float_as_int(qb2.w));
             Vn.sti(V_PID, o, V.ldi(V_PID, slot));
-            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((W.R.ldi(R_FLG, slot) & RF_WROTE) << 16));
+            Vn.sti(V_MAT, o, (h.shade & 0xFFFF) | ((__float_as_int(qb2.z) & RF_WROTE) << 16));
             Vn.stf(V_IOR, o, h.ior);
         }
         outCount += total;
