@@ -151,6 +151,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                 NodeQ nd = nodes[cur];
 #if HRT_LOOKAHEAD
                 NodeQ nd1 = nodes[cur < last ? cur + 1 : cur];
+                __builtin_amdgcn_sched_barrier(0);           // all four loads leave before the first box test waits on one of them
 #endif
 #ifdef HRT_EXTRA_LOAD      // experiment: one more 16-byte load per node visit (is the walk bound by L1 accesses?)
                 { const float4* q = &nodes[cur].hi; asm volatile("" : "+v"(q)); float4 x = *q; nd.hi.x = __builtin_fminf(nd.hi.x, x.x); }
@@ -162,24 +163,23 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     int sk = wbits(nd.hi);
                     const int cnt = (int)((unsigned)sk >> 28);
                     sk &= kEnd;
-                    bool again = false;
+                    const int here = cur;
+                    bool stay = true;                    // still walking nodes of the same tree after this node
                     if (!hit_box(w, nd.lo, nd.hi, 0.001f, lim)) cur = sk;
                     else if (cnt > 0)
                     {
+                        stay = false;
                         if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
                         else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
                     }
-                    else
-                    {
-                        const int link = wbits(nd.lo) & kEnd;
-                        again = (k == 0) && HRT_LOOKAHEAD && link == cur + 1 && cur < last;
-                        cur = link;
-                    }
+                    else cur = wbits(nd.lo) & kEnd;
 #if HRT_LOOKAHEAD
-                    if (!again) break;
+                    // the record after `here` is the next node after a hit on an inner node AND after a missed leaf (a
+                    // leaf's skip link is its successor in walk order): only a missed inner node jumps elsewhere
+                    if (!(k == 0 && stay && cur == here + 1 && here < last)) break;
                     nd = nd1;
 #else
-                    (void)again;
+                    (void)here; (void)stay;
 #endif
                 }
             }
