@@ -115,7 +115,7 @@ constexpr int kWalkBlocksPerCU = HRT_WALK_BLOCKS_PER_CU;
 #define HRT_CHAIN_FEAT0 0
 #endif
 #ifndef HRT_WF_TRACE_WAVES
-#define HRT_WF_TRACE_WAVES 8
+#define HRT_WF_TRACE_WAVES 4
 #endif
 template <class TR, bool COUNT>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
@@ -933,25 +933,11 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         // device-private repack (TracerPacked)
         const void* psrc[4] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data()};
         const size_t pbytes[4] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri)};
-#ifdef HRT_REPL
-        for (int i = 0; i < 4; i++)
-        {
-            const size_t padded = ((pbytes[i] + 4096 + 767) / 768) * 768;        // multiple of both record sizes
-            HIPCHK(c, hipMalloc(&d.packed[i], padded * HRT_REPL));
-            for (int r = 0; r < HRT_REPL; r++)
-                HIPCHK(c, hipMemcpyAsync((char*)d.packed[i] + padded * r, psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
-        }
-        d.dpacked.stride[0] = (long long)((((pbytes[0] + 4096 + 767) / 768) * 768) / sizeof(NodeQ));
-        d.dpacked.stride[1] = (long long)((((pbytes[1] + 4096 + 767) / 768) * 768) / sizeof(FInst));
-        d.dpacked.stride[2] = (long long)((((pbytes[2] + 4096 + 767) / 768) * 768) / sizeof(NodeQ));
-        d.dpacked.stride[3] = (long long)((((pbytes[3] + 4096 + 767) / 768) * 768) / sizeof(FTri));
-#else
         for (int i = 0; i < 4; i++)
         {
             HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
         }
-#endif
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
         d.dpacked.nTlas = (int)ph.tlas.size();

@@ -42,9 +42,6 @@ struct DPacked {
     const NodeQ* blas;       // indexed like blasNodes
     const FTri* ftri;        // indexed like triPrimIdx
     int nTlas;               // records in tlas (>= 1)
-#ifdef HRT_REPL              // experiment: HRT_REPL copies of every array, element strides below
-    long long stride[4];
-#endif
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514

@@ -25,22 +25,10 @@ enum { M_IDLE = 0, M_TLAS = 1, M_TLEAF = 2, M_BLAS = 3, M_BLEAF = 4, M_DONE = 5 
 #endif
 constexpr int kRefillMin = HRT_REFILL_MIN;      // refill when at least this many lanes are idle (or none is active)
 constexpr int kNodeBurst = 6;       // max node steps per iteration while most lanes are still walking
-// Leaf phases run with few live lanes (a ray spends ~5-15 % of its steps on leaf entries), yet cost a full wave
-// instruction stream each time.  They are therefore gated: lanes standing on a leaf entry wait until enough of them
-// have gathered, or until too few lanes are left walking nodes to keep the wave busy.
-#ifndef HRT_GATE_T
-#define HRT_GATE_T 1
-#endif
-#ifndef HRT_GATE_B
-#define HRT_GATE_B 1
-#endif
-#ifndef HRT_WALK_LOW
-#define HRT_WALK_LOW 24
-#endif
 #ifndef HRT_LOOKAHEAD
-#define HRT_LOOKAHEAD 1
+#define HRT_LOOKAHEAD 2             // records fetched per node step (1 = no lookahead)
 #endif
-constexpr int kGateT = HRT_GATE_T, kGateB = HRT_GATE_B, kWalkLow = HRT_WALK_LOW;
+constexpr int kLook = HRT_LOOKAHEAD;
 
 struct WalkResult { float t, tObj; int slot, prim; bool occluded; };
 
@@ -69,12 +57,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
     constexpr bool kAlpha = (FEAT & 2) != 0;
     __shared__ float park_mem[kGeneral ? 9 : 1][256];
     RayPark park; park.sh = park_mem;
-#ifdef HRT_REPL
-    DPacked P = tr.P;
-    { const int cp = (int)((blockIdx.x >> 3) % HRT_REPL); P.tlas += cp * P.stride[0]; P.finst += cp * P.stride[1]; P.blas += cp * P.stride[2]; P.ftri += cp * P.stride[3]; }
-#else
     const DPacked& P = tr.P;
-#endif
     const DScene& S = tr.S;
     Tex tex(S);
     const int lane = threadIdx.x & 63;
@@ -148,17 +131,16 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                 // 128-byte line: it is fetched together with the node itself, so a hit costs no second memory round trip
                 // (the walk is bound by the latency of dependent loads, not by their number).
                 const int last = (top ? P.nTlas : blasEnd) - 1;
-                NodeQ nd = nodes[cur];
-#if HRT_LOOKAHEAD
-                NodeQ nd1 = nodes[cur < last ? cur + 1 : cur];
-                __builtin_amdgcn_sched_barrier(0);           // all four loads leave before the first box test waits on one of them
-#endif
-#ifdef HRT_EXTRA_LOAD      // experiment: one more 16-byte load per node visit (is the walk bound by L1 accesses?)
-                { const float4* q = &nodes[cur].hi; asm volatile("" : "+v"(q)); float4 x = *q; nd.hi.x = __builtin_fminf(nd.hi.x, x.x); }
-#endif
+                // kLook consecutive records leave together (one or two 128-byte lines)
+                NodeQ nds[kLook];
+#pragma unroll
+                for (int k = 0; k < kLook; k++) nds[k] = nodes[cur + k <= last ? cur + k : last];
+                __builtin_amdgcn_sched_barrier(0);           // all loads leave before the first box test waits on one of them
                 const float lim = top ? (ANY ? tMaxW : bestT) : (ANY ? tMaxW * iscale : tObj);
-                for (int k = 0; k < (HRT_LOOKAHEAD ? 2 : 1); k++)
+#pragma unroll
+                for (int k = 0; k < kLook; k++)
                 {
+                    const NodeQ nd = nds[k];
                     C.inc(C_NODE_VISITS);
                     int sk = wbits(nd.hi);
                     const int cnt = (int)((unsigned)sk >> 28);
@@ -173,14 +155,9 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                         else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
                     }
                     else cur = wbits(nd.lo) & kEnd;
-#if HRT_LOOKAHEAD
                     // the record after `here` is the next node after a hit on an inner node AND after a missed leaf (a
                     // leaf's skip link is its successor in walk order): only a missed inner node jumps elsewhere
-                    if (!(k == 0 && stay && cur == here + 1 && here < last)) break;
-                    nd = nd1;
-#else
-                    (void)here; (void)stay;
-#endif
+                    if (!(stay && cur == here + 1 && here < last)) break;
                 }
             }
             // walk ends
@@ -200,23 +177,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
 
         WTIME(13);
         // ---------------- one TLAS leaf entry
-        bool runT = true, runB = true;
-        if (kGateT > 1 || kGateB > 1)
-        {
-            const int nWalkNow = __popcll(__ballot((mode == M_TLAS) || (kGeneral && mode == M_BLAS)));
-            const int nT = __popcll(__ballot(mode == M_TLEAF));
-            runT = nT >= kGateT || nWalkNow < kWalkLow;
-            if (kGeneral)
-            {
-                const int nB = __popcll(__ballot(mode == M_BLEAF));
-                runB = nB >= kGateB || nWalkNow < kWalkLow;
-            }
-        }
 #ifdef HRT_WALK_STATS
-        { const int a = __popcll(__ballot(runT && mode == M_TLEAF)); if (a) { WSTAT(3, 1); WSTAT(4, a); }
-          const int b = __popcll(__ballot(kGeneral && runB && mode == M_BLEAF)); if (b) { WSTAT(5, 1); WSTAT(6, b); } }
+        { const int a = __popcll(__ballot(mode == M_TLEAF)); if (a) { WSTAT(3, 1); WSTAT(4, a); }
+          const int b = __popcll(__ballot(kGeneral && mode == M_BLEAF)); if (b) { WSTAT(5, 1); WSTAT(6, b); } }
 #endif
-        if (runT && mode == M_TLEAF)
+        if (mode == M_TLEAF)
         {
             FInst f = P.finst[li];
             C.inc(C_LEAF_INST);
@@ -253,7 +218,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
 
         WTIME(14);
         // ---------------- one BLAS leaf entry
-        if (kGeneral && runB && mode == M_BLEAF)
+        if (kGeneral && mode == M_BLEAF)
         {
             const float lim = ANY ? tMaxW * iscale : tObj;
             if (iflags & FI_SPHERESET)
