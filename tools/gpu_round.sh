@@ -23,3 +23,15 @@ for c in 2 3; do
   timeout -k 10 900 python tools/collect_traffic.py --config $c --dir $OUT/traffic --out $OUT/traffic_config$c.json > $OUT/traffic_c$c.log 2>&1; echo "traffic rc=$?" | tee -a $OUT/progress.log
   grep hbm_bytes_per_launch $OUT/traffic_config$c.json | tee -a $OUT/progress.log
 done
+echo "== bench + kernel stats config 4 (4 spp of 64)" | tee -a $OUT/progress.log
+timeout -k 10 600 python bench.py --config 4 --spp 4 --cpu-seconds 0 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "bench rc=$?" | tee -a $OUT/progress.log
+cat $OUT/bench_c4.json | tee -a $OUT/progress.log
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c4 -- python bench.py --config 4 --spp 4 --steps 10 --warmup 2 --cpu-seconds 0 > $OUT/prof_bench_c4.json 2> $OUT/prof_c4.err; echo "rocprof rc=$?" | tee -a $OUT/progress.log
+python tools/kstats.py $OUT/prof_c4 | head -12 | tee -a $OUT/progress.log
+echo "== all configs, kernel organisations" | tee -a $OUT/progress.log
+timeout -k 10 600 python tools/ab_bench.py --configs 2,3,4,5 --frames 5 2>&1 | tee -a $OUT/progress.log
+STATS=ilgpu_raytracing_amd/csrc/variants/libhip_raytrace_stats.so
+if [ -e $STATS ]; then
+  echo "== walker phase statistics (variant build -DHRT_WALK_STATS)" | tee -a $OUT/progress.log
+  HRT_LIB=$PWD/$STATS timeout -k 10 300 python tools/walk_stats.py --configs 3,4,5 2>&1 | tee $OUT/walker_phase_stats.txt | tee -a $OUT/progress.log
+fi
