@@ -71,6 +71,11 @@ MODES = {
     "mega_packed": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL,
     "stream_reflayout": T.FLAG_COUNTERS | T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT,
     "mega_reflayout": T.FLAG_COUNTERS | T.FLAG_MEGAKERNEL | T.FLAG_REFERENCE_LAYOUT,
+    # the kernels a host runs in production are the non-counting instantiations (other register allocation, the
+    # chained walk launches take the same code path): they get the same check, minus the counters
+    "auto_production": 0,
+    "stream_production": T.FLAG_STREAMED,
+    "mega_production": T.FLAG_MEGAKERNEL,
 }
 
 
@@ -85,9 +90,13 @@ def test_frame_matches_oracle(orc, renderer, name, mode):
     _check_radiance_tolerance(ref, got)
     # reservoirs: resCur is written only where a diffuse vertex was reached; both start from zeros
     H.assert_outputs_equal(ref, got, names=H.RES_NAMES)
-    for i in range(2):
-        assert gst.k[i].as_dict() == ost.k[i].as_dict(), "work counters of launch %d" % i
-    assert gst.counters_valid == 1 and gst.n_devices == 1
+    if MODES[mode] & T.FLAG_COUNTERS:
+        for i in range(2):
+            assert gst.k[i].as_dict() == ost.k[i].as_dict(), "work counters of launch %d" % i
+        assert gst.counters_valid == 1
+    else:
+        assert gst.counters_valid == 0
+    assert gst.n_devices == 1
 
 
 def test_streamed_sample_batches(orc, renderer, monkeypatch):
