@@ -144,7 +144,7 @@ class DeviceViews(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("row_begin", "row_end", "strip_n", "strip_i", "width", "height", "device_id", "reserved")] + \
                [(n, C.c_void_p) for n in ("color", "depth", "objectId", "radiance", "gb_worldPos", "gb_normalWS",
                                           "gb_baseColor", "gb_matId", "gb_objId", "gb_hitMask", "present_color")] + \
-               [("present_width", C.c_int32), ("present_height", C.c_int32)]
+               [("present_width", C.c_int32), ("present_height", C.c_int32), ("res_a", C.c_void_p * 7), ("res_b", C.c_void_p * 7)]
 
 
 class PresentParams(C.Structure):
@@ -161,6 +161,8 @@ FLAG_REFERENCE_LAYOUT = 4
 FLAG_NO_SYNC = 8
 FLAG_MEGAKERNEL = 16
 FLAG_STREAMED = 32
+FLAG_PRIMARY_ONLY = 64
+FLAG_EXCHANGED = 128
 
 SHADING_LAMBERT, SHADING_MIRROR, SHADING_GLASS = 0, 1, 2
 BLAS_SPHERESET, BLAS_TRIMESH = 1, 2

@@ -988,9 +988,11 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     if (nosync && out) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: HRT_FLAG_NO_SYNC frames cannot gather to host (outputs must be NULL)");
     const bool reuse = (p->enableTemporalReuse != 0 || p->enableSpatialReuse != 0);
     const int nd = (int)c->dev.size();
-    if (reuse && (sn > 1 || rb != 0 || re != p->height))
-        return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse needs every pixel's G-buffer and previous reservoir: render reuse frames as full images "
-                    "(one ctx over several devices exchanges tiles itself; per-process tiles would need an inter-process exchange)");
+    const bool primaryOnly = (flags & HRT_FLAG_PRIMARY_ONLY) != 0;
+    if (primaryOnly && (flags & HRT_FLAG_SKIP_PRIMARY)) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: PRIMARY_ONLY and SKIP_PRIMARY exclude each other");
+    if (reuse && !primaryOnly && !(flags & HRT_FLAG_EXCHANGED) && (sn > 1 || rb != 0 || re != p->height))
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: ReSTIR reuse needs every pixel's G-buffer and previous reservoir: render reuse frames as full images, "
+                    "or exchange tiles between processes and say so (HRT_FLAG_PRIMARY_ONLY / HRT_FLAG_EXCHANGED; one ctx over several devices exchanges tiles itself)");
     if (reuse && nd > 1 && nosync) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: multi-device reuse frames cannot be enqueued with HRT_FLAG_NO_SYNC");
     const int64_t nPix = (int64_t)p->width * p->height;
     const bool count = (flags & HRT_FLAG_COUNTERS) != 0;
@@ -1118,13 +1120,13 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         DReservoir resPrev = even ? d.resB : d.resA;
         DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
-        int rcs = with_tracer(d, [&](auto tr) -> int {
+        int rcs = primaryOnly ? HRT_OK : with_tracer(d, [&](auto tr) -> int {
             return run_path_stage(c, d, tr, k, tm, p->width, resPrev, resCur, (long long)nPix, count, mega);
         });
         if (rcs != HRT_OK) return rcs;
         HIPCHK(c, hipEventRecord(ev[2], d.stream));
     }
-    if (exchange)
+    if (exchange && !primaryOnly)
     {   // next frame's resPrev must be complete on every device (temporal reprojection can land anywhere, RTRay.cs:339-360)
         int rc = exchange_arrays(2, [&](DeviceState& src, DeviceState& dst) -> int {
             const DReservoir& a = even ? src.resA : src.resB;
@@ -1233,6 +1235,13 @@ int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
     o->gb_worldPos = d.gb.worldPos; o->gb_normalWS = d.gb.normalWS; o->gb_baseColor = d.gb.baseColor;
     o->gb_matId = d.gb.matId; o->gb_objId = d.gb.objId; o->gb_hitMask = d.gb.hitMask;
     o->present_color = d.present_color; o->present_width = d.present_w; o->present_height = d.present_h;
+    const DReservoir* rs[2] = {&d.resA, &d.resB};
+    void** dst[2] = {o->res_a, o->res_b};
+    for (int i = 0; i < 2; i++)
+    {
+        dst[i][0] = rs[i]->L; dst[i][1] = rs[i]->wi; dst[i][2] = rs[i]->pdf; dst[i][3] = rs[i]->w;
+        dst[i][4] = rs[i]->wSum; dst[i][5] = rs[i]->m; dst[i][6] = rs[i]->lightId;
+    }
     return HRT_OK;
 }
 

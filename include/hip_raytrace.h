@@ -81,8 +81,17 @@ enum hrt_render_flags {
     HRT_FLAG_MEGAKERNEL   = 1u << 4,  /* force the path-trace launch to run as ONE one-pixel-per-lane kernel      */
     HRT_FLAG_STREAMED     = 1u << 5,  /* force the streamed init/shade/walk/finish/resolve pipeline.  Neither flag:
                                          the library picks by scene size (tiny BVH -> fused).  Identical results.  */
-    HRT_FLAG_NO_SYNC      = 1u << 3   /* enqueue only (outputs must be NULL); collect with hrt_synchronize.
+    HRT_FLAG_NO_SYNC      = 1u << 3,  /* enqueue only (outputs must be NULL); collect with hrt_synchronize.
                                          Up to 128 frames may be in flight; the 129th call drains first.      */
+    /* One process per GPU with ReSTIR reuse ON: a tile needs the current G-buffer (worldPos, normalWS, objId) and the
+     * previous reservoirs of the WHOLE image (RTRay.cs:339-374, 488-515).  The host then renders a frame in two calls
+     * with an all-gather after each (ilgpu_raytracing_amd/tiling.py, RCCL through torch.distributed):
+     *   1. HRT_FLAG_PRIMARY_ONLY            launch 1 on this tile           -> all-gather the 3 G-buffer arrays
+     *   2. HRT_FLAG_SKIP_PRIMARY|EXCHANGED  path-trace launch on this tile  -> all-gather the 7 arrays of resCur
+     * through the device pointers of hrt_device_buffers.  EXCHANGED is the caller's statement that both all-gathers of
+     * the protocol are done; without it a reuse frame on a partial tile is refused (HRT_ERR_INVALID_STATE).        */
+    HRT_FLAG_PRIMARY_ONLY = 1u << 6,
+    HRT_FLAG_EXCHANGED    = 1u << 7
 };
 
 /* Host destinations of one frame; any pointer may be NULL (not copied).  Arrays hold
@@ -133,6 +142,9 @@ typedef struct hrt_device_views {
     void *gb_worldPos, *gb_normalWS, *gb_baseColor, *gb_matId, *gb_objId, *gb_hitMask;
     void *present_color;                      /* display-size RGBA8 of the last hrt_present (NULL before) */
     int32_t present_width, present_height;
+    /* reservoir sets A and B (GpuReservoirSoA, RTRay.cs:23-48): L, wi (float3), pdf, w, wSum (float), m, lightId (int).
+     * Frame f writes resCur = A and reads resPrev = B when f is even, the other way round when odd (Framebuffer.cs:132-145) */
+    void *res_a[7], *res_b[7];
 } hrt_device_views;
 
 /* Presentation step of RenderDirectToPbo after the two launches (RTRenderer.cs:208-231): the last frame

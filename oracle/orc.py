@@ -163,11 +163,12 @@ class OrcScene:
 
 
 def render_frame(scene_desc, params, out_struct, prev_struct=None, row_begin=0, row_end=0, run_primary=True, nthreads=None):
-    """Runs PrimaryVisibilityKernel + PathTraceKernel of the oracle.  Returns Stats."""
+    """Runs PrimaryVisibilityKernel + PathTraceKernel of the oracle.  Returns Stats.
+    run_primary: True both launches, False launch 2 only (G-buffer as given), 2 launch 1 only."""
     st = T.Stats()
     if nthreads is None:
         nthreads = min(os.cpu_count() or 1, 64)
-    rc = lib().orc_render_frame(C.byref(scene_desc), C.byref(params), row_begin, row_end, 1 if run_primary else 0, nthreads,
+    rc = lib().orc_render_frame(C.byref(scene_desc), C.byref(params), row_begin, row_end, 2 if run_primary == 2 else (1 if run_primary else 0), nthreads,
                                 C.byref(out_struct), C.byref(prev_struct) if prev_struct is not None else None, C.byref(st))
     if rc != 0:
         raise RuntimeError("orc_render_frame failed (%d)" % rc)

@@ -133,6 +133,7 @@ int orc_render_frame(const hrt_scene_desc* scene, const hrt_frame_params* fp,
         st.kernel_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
+    if (run_primary != 2)        // 2 = launch 1 only (tile-exchange tests: the G-buffer is exchanged between the launches)
     {
         GpuFramebuffer fb;
         fb.color = av(out->color, P); fb.depth = av(out->depth, P); fb.objectId = av(out->objectId, P);

@@ -68,3 +68,91 @@ def test_two_rank_row_tiling_gloo(tmp_path):
                           "--master-port", str(29500 + os.getpid() % 500), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "TILING_OK 2" in out.stdout
+
+
+def test_strip_rows_partition_the_image():
+    for h in (1, 8, 9, 37, 270, 1080):
+        for n in (1, 2, 3, 8):
+            rows = np.concatenate([tiling.strip_rows(h, n, r) for r in range(n)])
+            assert sorted(rows.tolist()) == list(range(h))
+    assert tiling.strip_rows(37, 3, 1).tolist() == list(range(8, 16)) + list(range(32, 37))
+
+
+def test_pack_unpack_rows_roundtrip():
+    rng = np.random.RandomState(3)
+    h, w = 37, 5
+    src = [rng.rand(h, w * 3).astype(np.float32), rng.randint(-5, 5, (h, w)).astype(np.int32), rng.rand(h, w).astype(np.float32)]
+    src[0][3, 4] = -0.0; src[0][5, 1] = np.nan                                 # bytes travel, not values
+    dst = [np.zeros_like(a) for a in src]
+    for r in range(3):
+        rows = tiling.strip_rows(h, 3, r)
+        tiling.unpack_rows(dst, rows, 16, tiling.pack_rows(src, rows, 16))
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(src, dst))
+
+
+REUSE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from ilgpu_raytracing_amd import _types as T, scenes, tiling
+from oracle import orc
+from tests import helpers as H
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cfg = scenes.CONFIGS[2]; w, h, spp = 64, 44, 1            # 6 strips, the last one 4 rows: ragged tiles
+so = orc.OrcScene(); scenes.build_config2(so)
+arrs, o = T.alloc_outputs(w, h)                            # this rank's "device" arrays (whole image, only its strips valid)
+A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+full, fo = T.alloc_outputs(w, h)                           # rank 0 also renders the full image for comparison
+FA, FB = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+prev_cam = None
+for f in range(3):
+    origin = (0.2 * f, 1.5, 5.5 - 0.15 * f)                # moving camera: temporal reprojection crosses tiles
+    c2 = scenes.Config("mv", w, h, spp, origin, cfg.cam_lookat, extra=cfg.extra)
+    p = scenes.frame_params(c2, *H.host_funcs("orc", orc), frame=f, reuse=True, prev_cam=prev_cam)
+    prev, cur = (B, A) if f %% 2 == 0 else (A, B)
+    for k, a in cur.items():
+        arrs[k] = a; setattr(o, k, a.ctypes.data)
+    po = T.Outputs()
+    for k, a in prev.items():
+        setattr(po, k, a.ctypes.data)
+    strips = range(rank, (h + 7) // 8, world)
+    for s in strips:                                       # launch 1 on this rank's strips
+        orc.render_frame(so.desc(), p, o, po, row_begin=8 * s, row_end=min(h, 8 * s + 8), run_primary=2, nthreads=1)
+    gb = [arrs[n].reshape(h, -1) for n, _, _ in tiling.GBUFFER_EXCHANGE]
+    tiling.all_gather_strips(gb, h, world, rank)
+    for s in strips:                                       # launch 2 on this rank's strips, G-buffer and resPrev complete
+        orc.render_frame(so.desc(), p, o, po, row_begin=8 * s, row_end=min(h, 8 * s + 8), run_primary=False, nthreads=1)
+    tiling.all_gather_strips([cur["res_" + n].reshape(h, -1) for n, _, _ in tiling.RESERVOIR_FIELDS], h, world, rank)
+    if rank == 0:
+        fprev, fcur = (FB, FA) if f %% 2 == 0 else (FA, FB)
+        for k, a in fcur.items():
+            full[k] = a; setattr(fo, k, a.ctypes.data)
+        fpo = T.Outputs()
+        for k, a in fprev.items():
+            setattr(fpo, k, a.ctypes.data)
+        orc.render_frame(so.desc(), p, fo, fpo, nthreads=1)
+        mine = tiling.strip_rows(h, world, 0)
+        for k in ("color", "radiance", "depth"):
+            assert np.array_equal(arrs[k].reshape(h, -1)[mine], full[k].reshape(h, -1)[mine], equal_nan=True), (f, k)
+        for k in H.RES_NAMES + ["gb_worldPos", "gb_normalWS", "gb_objId"]:
+            assert arrs[k].tobytes() == full[k].tobytes(), (f, k)     # whole image after the exchange
+    prev_cam = T.Camera.from_buffer_copy(bytes(p.cam))
+if rank == 0:
+    print("REUSE_TILING_OK", world)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_reuse_tile_exchange_gloo(tmp_path):
+    """The exchange protocol of tiling.render_reuse_frame (launch 1 -> all-gather G-buffer -> launch 2 -> all-gather
+    resCur) driven with the oracle as the tile renderer on two gloo ranks: 3 reuse frames with a moving camera end up
+    byte-identical to full-image frames."""
+    script = tmp_path / "reuse_worker.py"
+    script.write_text(REUSE_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29000 + os.getpid() % 500), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "REUSE_TILING_OK 2" in out.stdout
