@@ -241,7 +241,7 @@ struct DeviceState {
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
-    void* packed[4] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri (device-private repack)
+    void* packed[5] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
     DPacked dpacked{};
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
@@ -268,6 +268,7 @@ struct hrt_ctx {
     bool scene_ready = false;
     bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
     int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
+    int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
     bool small_scene = false;                  // <= kSmallSceneNodes BVH nodes: the walk is ALU-bound and L1-resident -> megakernel
     int width = 0, height = 0;
 };
@@ -369,7 +370,7 @@ void free_workspace(DeviceState& d)
 void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
-    for (int i = 0; i < 4; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
+    for (int i = 0; i < 5; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -379,9 +380,10 @@ void free_scene(DeviceState& d)
 // fault or a walk that never ends.  (The reference trusts its own builder and checks nothing.)
 // ---------------------------------------------------------------------------------------
 struct PackedHost {
-    std::vector<NodeQ> tlas, blas;
+    std::vector<NodeQ> tlas, blas, flat;     // flat: the TLAS leaves in walk order (TracerFlat)
     std::vector<FInst> finst;
     std::vector<FTri> ftri;
+    int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
 };
@@ -470,9 +472,9 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     // a hit is the next node in memory, so a descent reads consecutive 32-byte records (4 per 128-byte line)
     // instead of jumping between the two halves of the builder's right-first numbering.  Pure permutation: every
     // walk visits the same nodes in the same order.  perm[old - lo] = new - lo.
-    auto walk_order = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, int64_t root, std::vector<int32_t>& perm) {
+    auto walk_order = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, int64_t root, std::vector<int32_t>& perm) -> int32_t {   // returns the number of reachable nodes
         const size_t n = (size_t)(hi - lo);
-        if (getenv("HRT_BUILDER_ORDER")) { perm.resize(n); for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i; return; }   // A/B knob
+        if (getenv("HRT_BUILDER_ORDER")) { perm.resize(n); for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i; return -1; }   // A/B knob
         perm.assign(n, -1);
         int32_t next = 0;
         std::vector<int64_t> st;
@@ -486,7 +488,9 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             st.push_back(b.skipIndex);
             if (b.count <= 0) st.push_back(b.left);
         }
+        const int32_t reachable = next;
         for (size_t i = 0; i < n; i++) if (perm[i] < 0) perm[i] = next++;        // unreachable nodes keep a slot
+        return reachable;
     };
     auto pack_range = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, const std::vector<int32_t>& perm, std::vector<NodeQ>& dst) {
         auto remap = [&](int32_t link) -> int { return (link < lo || link >= hi) ? kEnd : (int)(lo + perm[(size_t)(link - lo)]); };
@@ -510,7 +514,8 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     };
     std::vector<int32_t> perm;
     alloc_nodes(nT, out.tlas);
-    if (nT > 0) { walk_order(s->tlasNodes, 0, nT, 0, perm); pack_range(s->tlasNodes, 0, nT, perm, out.tlas); }
+    int32_t reachableT = -1;
+    if (nT > 0) { reachableT = walk_order(s->tlasNodes, 0, nT, 0, perm); pack_range(s->tlasNodes, 0, nT, perm, out.tlas); }
     alloc_nodes(nB, out.blas);
     {
         // every instance owns the node range [blasRoot, blasRoot + blasNodeCount); each distinct range is renumbered
@@ -600,6 +605,17 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         o.v0 = mkf4(a.X, a.Y, a.Z, bits_f(ti));
         o.v1 = mkf4(b.X, b.Y, b.Z, bits_f(mi));
         o.v2 = mkf4(c.X, c.Y, c.Z, bits_f(fl));
+    }
+    // TracerFlat: the reachable TLAS leaves in walk order, for scenes made of fast-sphere instances only
+    out.flat.assign(1, NodeQ{});
+    if (out.ok && out.feat == 0 && reachableT > 0)
+    {
+        std::vector<NodeQ> leaves;
+        for (int32_t i = 0; i < reachableT; i++)
+            if (((unsigned)__builtin_bit_cast(int, out.tlas[(size_t)i].hi.w) >> 28) != 0) leaves.push_back(out.tlas[(size_t)i]);
+        if (!leaves.empty() && (int)leaves.size() <= kFlatMaxLeaves) out.flat = leaves;
+        else out.flat.clear(), out.flat.assign(1, NodeQ{});
+        out.n_flat = (!leaves.empty() && (int)leaves.size() <= kFlatMaxLeaves) ? (int)leaves.size() : 0;
     }
     return "";
 }
@@ -905,6 +921,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->packed_ok = ph.ok;
     c->packed_feat = (ph.feat & 2) ? 3 : (ph.feat & 1);
     c->small_scene = (s->n_tlasNodes + s->n_blasNodes) <= kSmallSceneNodes;
+    c->flat_leaves = ph.n_flat;
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
     for (DeviceState& d : c->dev)
@@ -931,9 +948,10 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
         // device-private repack (TracerPacked)
-        const void* psrc[4] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data()};
-        const size_t pbytes[4] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri)};
-        for (int i = 0; i < 4; i++)
+        const void* psrc[5] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data()};
+        const size_t pbytes[5] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
+                                  ph.flat.size() * sizeof(NodeQ)};
+        for (int i = 0; i < 5; i++)
         {
             HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
@@ -1046,7 +1064,11 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     const bool usePacked = c->packed_ok && !(flags & HRT_FLAG_REFERENCE_LAYOUT);
     const int variant = usePacked ? c->packed_feat : -1;
     const bool mega = (flags & HRT_FLAG_MEGAKERNEL) ? true : ((flags & HRT_FLAG_STREAMED) ? false : c->small_scene);
+    // production frames of a tiny fast-sphere scene in the fused kernel: wave-uniform sweep over the TLAS leaves
+    static const bool noFlat = getenv("HRT_NO_FLAT") != nullptr;       // A/B knob
+    const bool flat = variant == 0 && mega && !count && c->flat_leaves > 0 && !noFlat;
     auto with_tracer = [&](DeviceState& d, auto fn) -> int {
+        if (flat) { TracerFlat t; t.tree.P = d.dpacked; t.tree.S = d.dscene; t.leaves = (const NodeQ*)d.packed[4]; t.nLeaves = c->flat_leaves; return fn(t); }
         if (variant == 0)      { TracerPackedT<0> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }
         else if (variant == 1) { TracerPackedT<1> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }
         else if (variant == 3) { TracerPackedT<3> t; t.P = d.dpacked; t.S = d.dscene; return fn(t); }

@@ -478,4 +478,81 @@ struct TracerPackedT {
 };
 using TracerPacked = TracerPackedT<3>;       // everything compiled in
 
+// ---------------------------------------------------------------------------------------
+// TracerFlat: scenes whose TLAS has a handful of leaves and only fast-sphere instances (the
+// reference's default scene, BASELINE config 2).  The tree walk of such a scene is a few
+// divergent dependent loads per ray; here every lane runs ONE wave-uniform loop over the
+// TLAS LEAVES in walk order instead: leaf records and instance records are read through
+// the scalar cache into SGPRs (uniform addresses), lanes differ only in their exec mask.
+//
+// Same results as the tree walk, by construction of the reference's own tests:
+//  * a leaf is entered iff every box on its root path and its own box pass IntersectAABB
+//    (SceneDeviceViews.cs:496-514) with the closest t of that moment; a parent's box contains
+//    its children's (bounds are unions, exact in binary32), and in that slab test enlarging
+//    a box can only turn a miss into a hit (every operation is monotone in the bound) while
+//    the closest t only shrinks along the walk: so a leaf whose own test passes has passed
+//    all its ancestors' tests -- inner nodes only accelerate, the leaf's own test decides;
+//  * leaves are visited in the same order, so the closest t each leaf test sees, every
+//    tie-break and the first any-hit are the same.
+// Monotonicity needs finite slab arithmetic: a ray whose origin or 1/d is not finite (d
+// component denormal) takes the tree walk.  Work counters are those of the tree walk and are
+// not produced here: counting frames use TracerPackedT<0>.
+// ---------------------------------------------------------------------------------------
+constexpr int kFlatMaxLeaves = 16;
+struct TracerFlat {
+    TracerPackedT<0> tree;
+    const NodeQ* leaves;         // TLAS leaf records in walk order
+    int nLeaves;
+
+    HRT_D static bool finite_ray(const Ray& r)
+    {
+        return hrt_isfinite(r.inv.x) && hrt_isfinite(r.inv.y) && hrt_isfinite(r.inv.z) &&
+               hrt_isfinite(r.o.x) && hrt_isfinite(r.o.y) && hrt_isfinite(r.o.z);
+    }
+
+    template <bool COUNT>
+    HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
+    {
+        if (COUNT || !finite_ray(wray)) return tree.template closest<COUNT>(wray, best, C);
+        float bestT = 1e30f; int bestSlot = -1, bestPrim = -1;
+        for (int l = 0; l < nLeaves; l++)
+        {
+            const NodeQ n = leaves[l];
+            if (!hit_box(wray, n.lo, n.hi, 0.001f, bestT)) continue;
+            const int first = wbits(n.lo), cnt = (int)((unsigned)wbits(n.hi) >> 28);
+            for (int i = first; i < first + cnt; i++)
+            {
+                const FInst f = tree.P.finst[i];
+                if (!hit_box(wray, f.a, f.b, 0.001f, 1e30f)) continue;
+                float t;
+                if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < 1e30f && t < 1e29f && t < bestT)
+                { bestT = t; bestSlot = i; bestPrim = wbits(f.b); }
+            }
+        }
+        return tree.finish_hit(wray, bestT, bestT, bestSlot, bestPrim, best);
+    }
+
+    template <bool COUNT>
+    HRT_D bool occluded(const Ray& wray, float tMaxWorld, Cnt<COUNT>& C) const
+    {
+        if (COUNT || !finite_ray(wray)) return tree.template occluded<COUNT>(wray, tMaxWorld, C);
+        bool hit = false;
+        for (int l = 0; l < nLeaves; l++)
+        {
+            const NodeQ n = leaves[l];
+            if (hit || !hit_box(wray, n.lo, n.hi, 0.001f, tMaxWorld)) continue;
+            const int first = wbits(n.lo), cnt = (int)((unsigned)wbits(n.hi) >> 28);
+            for (int i = first; i < first + cnt; i++)
+            {
+                const FInst f = tree.P.finst[i];
+                if (hit || !hit_box(wray, f.a, f.b, 0.001f, tMaxWorld)) continue;
+                float t;
+                if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < tMaxWorld) hit = true;
+            }
+            if (__builtin_amdgcn_ballot_w64(!hit) == 0) break;      // every live lane is occluded
+        }
+        return hit;
+    }
+};
+
 } // namespace hrt
