@@ -55,6 +55,7 @@ def lib():
         L.orc_hash3.argtypes = [C.c_uint32] * 3
         L.orc_pack_rgba8.argtypes = [C.c_float] * 3
         L.orc_math_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_hit_box.argtypes = [C.c_int] + [C.c_void_p] * 6
         L.orc_dotnet_sort_by_key.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_trace_rays.argtypes = [C.POINTER(T.SceneDesc), C.c_int] + [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 6
         L.orc_present.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -78,6 +79,15 @@ def math_eval(name, x, y=None):
     if y is not None:
         yy = np.ascontiguousarray(y, dtype=np.float32)
     lib().orc_math_eval(MATH_FN[name], x.size, x.ctypes.data, yy.ctypes.data if yy is not None else None, out.ctypes.data)
+    return out
+
+
+def hit_box(o, d, lo, hi, tmax):
+    """IntersectAABB of the oracle on arrays of rays (o, d: [n,3]) and boxes (lo, hi: [n,3]); tMin = 0.001."""
+    o, d, lo, hi = [np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 3) for a in (o, d, lo, hi)]
+    tm = np.ascontiguousarray(tmax, dtype=np.float32)
+    out = np.zeros(len(o), np.int32)
+    lib().orc_hit_box(len(o), o.ctypes.data, d.ctypes.data, lo.ctypes.data, hi.ctypes.data, tm.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -238,6 +238,17 @@ int orc_pack_rgba8(float r, float g, float b) { return GpuFramebuffer::PackRGBA8
 
 // fn: 0 sin 1 cos 2 tan 3 atan 4 atan2(x,y) 5 acos 6 asin 7 rsqrt 8 sqrt 9 fmin(x,y) 10 fmax(x,y)
 // 11 floor 12 round 13 f2i (as float bits of int) 14 1/x 15 x/y
+// IntersectAABB (SceneDeviceViews.cs:496-514) on n (ray, box, tMax) tuples: o/d 3 floats per ray (invDir derived as the
+// kernels do), lo/hi 3 floats per box.  Lets the tests check properties of the box test itself.
+void orc_hit_box(int n, const float* o, const float* d, const float* lo, const float* hi, const float* tmax, int32_t* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        Ray r; r.origin = Float3(o[3 * i], o[3 * i + 1], o[3 * i + 2]); r.dir = Float3(d[3 * i], d[3 * i + 1], d[3 * i + 2]); r.invDir = InvDir(r.dir);
+        out[i] = SceneDeviceViews::IntersectAABB(r, Float3(lo[3 * i], lo[3 * i + 1], lo[3 * i + 2]), Float3(hi[3 * i], hi[3 * i + 1], hi[3 * i + 2]), 0.001f, tmax[i]) ? 1 : 0;
+    }
+}
+
 void orc_math_eval(int fn, int n, const float* x, const float* y, float* out)
 {
     for (int i = 0; i < n; i++)

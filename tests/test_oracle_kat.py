@@ -369,3 +369,50 @@ def test_golden_fixtures(orc):
             assert np.all(H.bits_equal(want[k], got[k])), (name, k)
         meta = json.loads(str(want["counters_json"]))
         assert meta == [st.k[0].as_dict(), st.k[1].as_dict()]
+
+
+def test_box_test_is_monotone_in_the_box(orc):
+    """The property TracerFlat and the walker rest on: in IntersectAABB (SceneDeviceViews.cs:496-514)
+    enlarging the box, or raising tMax, never turns a hit into a miss -- so a leaf whose own test passes has passed the
+    tests of all its ancestors (their boxes are unions of their children's), and inner nodes only accelerate.
+    Adversarial cases: axis-parallel rays (1/d replaced by 1e8), origins exactly on box planes, flat boxes, boxes that
+    share planes with their parent, huge and tiny magnitudes.  Holds for finite slab arithmetic; rays whose 1/d is not
+    finite are routed to the tree walk by the kernels."""
+    rng = np.random.RandomState(11)
+    n = 400000
+    grid = np.array([-3.0, -1.0, -0.5, 0.0, 0.25, 0.5, 1.0, 2.0, 7.0], np.float32)
+
+    def pick(shape, p_grid):
+        v = (rng.rand(*shape).astype(np.float32) * 8 - 4)
+        g = grid[rng.randint(0, len(grid), shape)]
+        return np.where(rng.rand(*shape) < p_grid, g, v).astype(np.float32)
+
+    a, b = pick((n, 3), 0.5), pick((n, 3), 0.5)
+    clo, chi = np.minimum(a, b), np.maximum(a, b)
+    flat = rng.rand(n, 3) < 0.15
+    chi = np.where(flat, clo, chi)                                         # flat child boxes
+    grow_lo = np.where(rng.rand(n, 3) < 0.4, 0, np.abs(pick((n, 3), 0.5))).astype(np.float32)
+    grow_hi = np.where(rng.rand(n, 3) < 0.4, 0, np.abs(pick((n, 3), 0.5))).astype(np.float32)
+    plo, phi = (clo - grow_lo).astype(np.float32), (chi + grow_hi).astype(np.float32)   # parent shares planes 40 % of the time
+    o = pick((n, 3), 0.6)
+    on_plane = rng.rand(n, 3) < 0.2
+    o = np.where(on_plane, np.where(rng.rand(n, 3) < 0.5, clo, phi), o).astype(np.float32)   # origin exactly on a plane
+    d = pick((n, 3), 0.3)
+    d = np.where(rng.rand(n, 3) < 0.25, 0.0, d).astype(np.float32)         # axis-parallel components
+    d = np.where(rng.rand(n, 3) < 0.05, d * np.float32(1e-30), d).astype(np.float32)
+    scale = np.float32(10.0) ** rng.randint(-3, 4, (n, 1)).astype(np.float32)
+    clo, chi, plo, phi, o = [(x * scale).astype(np.float32) for x in (clo, chi, plo, phi, o)]
+    tmax_c = np.where(rng.rand(n) < 0.5, 1e30, rng.rand(n) * 20).astype(np.float32)
+    tmax_p = np.maximum(tmax_c, np.where(rng.rand(n) < 0.5, tmax_c, 1e30).astype(np.float32))
+    inv = 1.0 / np.where(d != 0, d, np.float32(1e-8)).astype(np.float32)
+    ok = np.isfinite(inv.astype(np.float32)).all(axis=1)
+    hc = orc.hit_box(o, d, clo, chi, tmax_c)
+    hp = orc.hit_box(o, d, plo, phi, tmax_p)
+    bad = np.nonzero((hc == 1) & (hp == 0) & ok)[0]
+    assert len(bad) == 0, (o[bad[0]], d[bad[0]], clo[bad[0]], chi[bad[0]], plo[bad[0]], phi[bad[0]], tmax_c[bad[0]], tmax_p[bad[0]])
+    assert hc.sum() > n // 50 and (hp.sum() - hc.sum()) > n // 100        # the sample exercises both outcomes
+    # why the kernels guard on finite 1/d: with a denormal direction component 1/d = inf and 0 * inf = NaN drops out of min/max
+    o1 = np.array([[1.0, 0.2, 0.3]], np.float32); d1 = np.array([[1e-40, 0.5, 0.8]], np.float32)
+    child = orc.hit_box(o1, d1, [[1.0, 0.0, 0.0]], [[1.0, 5.0, 5.0]], [1e30])[0]
+    parent = orc.hit_box(o1, d1, [[1.0, 0.0, 0.0]], [[2.0, 5.0, 5.0]], [1e30])[0]
+    assert (child, parent) == (1, 0)
