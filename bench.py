@@ -215,7 +215,10 @@ def main():
                        "rays_per_step": int(rays_total)},
             "roofline": {"bound": "hbm", "kernel": ("hrt_path_trace_kernel (fused)" if fused else "path-trace stage, streamed: hrt_wf_{init,shade,walk_shadow,walk_closest,finish,resolve}_kernel"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_total), "launch_ms": round(path_ms, 4)},
+                         "algorithmic_bytes_per_launch": int(bytes_total), "launch_ms": round(path_ms, 4),
+                         "note": "algorithmic bytes price every node / instance / primitive fetch of the reference algorithm as memory traffic "
+                                 "(SURVEY 8d); the trees are cache-resident, so achieved exceeds the HBM peak: the launch is VALU-bound, "
+                                 "measured HBM bytes per launch are in traffic"},
             "extra": {"primary_kernel_ms": round(prim_ms, 4), "path_trace_kernel_ms": round(path_ms, 4),
                       "step_ms_with_d2h_gather": round(d2h_step * 1e3, 4),
                       "mrays_per_s_with_d2h_gather": round(rays_total / d2h_step / 1e6, 2)},
