@@ -251,6 +251,38 @@ def build_textured_test_scene(b):
     b.load_mesh_instance(quad2)
 
 
+def rotation_affine(axis, degrees, scale=1.0, translate=(0.0, 0.0, 0.0)):
+    """Uniform scale * rotation about a coordinate axis + translation: the transforms Scene.InvertRigidOrUniform accepts."""
+    a = math.radians(degrees)
+    c, s_ = np.float32(math.cos(a)), np.float32(math.sin(a))
+    r = np.eye(3, dtype=np.float32)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[axis]
+    r[i, i] = c; r[j, j] = c; r[i, j] = -s_; r[j, i] = s_
+    r = (r * np.float32(scale)).astype(np.float32)
+    m = T.Affine3x4()
+    (m.m00, m.m01, m.m02), (m.m10, m.m11, m.m12), (m.m20, m.m21, m.m22) = [tuple(float(v) for v in row) for row in r]
+    m.m03, m.m13, m.m23 = [float(v) for v in translate]
+    return m
+
+
+def build_rotated_instances_scene(b):
+    """Rotated + uniformly scaled instances (TransformRay / TransformVector with a full 3x3, tWorld = tObj / scale, world
+    normal = normalize(objectToWorld * n)): a triangle grid, a multi-sphere BLAS and a single sphere, over a ground sphere."""
+    # all spheres first, instances afterwards, as Scene.BuildDefaultScene does: BuildBLAS_Spheres looks spheres up through the
+    # prim-index list by position (Scene.cs:386-390), which only equals the sphere id while no leaf has appended to that list
+    g = b.add_sphere(sphere((0.0, -300.0, 0.0), 300.0, (0.8, 0.8, 0.75)))
+    ids = [b.add_sphere(sphere((0.5 * i - 1.0, 0.2 * (i % 2), 0.3 * (i % 3)), 0.22, (0.9 - 0.1 * i, 0.3 + 0.1 * i, 0.4),
+                               T.SHADING_MIRROR if i == 2 else 0)) for i in range(6)]
+    gl = b.add_sphere(sphere((0.0, 0.0, 0.0), 0.5, (1.0, 1.0, 1.0), T.SHADING_GLASS, 1.5))
+    b.build_sphere_instance([g])
+    b.build_sphere_instance(ids, rotation_affine("z", -25.0, 0.8, (1.4, 0.9, 0.4)))
+    b.build_sphere_instance([gl], rotation_affine("x", 60.0, 1.2, (0.1, 0.65, 1.4)))
+    s = np.linspace(-1.0, 1.0, 7)
+    yq, xq = np.meshgrid(s, s, indexing="ij")
+    quad = grid_mesh(xq, yq, 0.2 * np.sin(2.0 * xq) * np.cos(1.5 * yq), (xq + 1) / 2, (yq + 1) / 2, kd=(0.3, 0.6, 0.9))
+    b.load_mesh_instance(quad, rotation_affine("y", 35.0, 1.4, (-1.2, 1.5, -0.6)))
+
+
 def build(cfg_id, b, **kw):
     {1: build_config1, 2: build_config2, 3: build_config3, 4: build_config4, 5: build_config5}[cfg_id](b, **kw)
     return CONFIGS[cfg_id]
