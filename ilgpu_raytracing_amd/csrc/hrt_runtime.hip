@@ -732,7 +732,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
     for (int b0 = 0; b0 < spp; b0 += (int)sb)
     {
-        HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
+        if (k.maxDepth > 0) HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
         g.batchStart = b0;
         g.batchCount = (int)std::min<long long>(sb, spp - b0);
         g.lastBatch = (b0 + g.batchCount >= spp) ? 1 : 0;

@@ -53,6 +53,7 @@ CASES = {
     "depth5_with_roulette": (scenes.build_config2, scenes.Config("rr", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 1.2, 0.0), max_depth=5,
                                                                   extra=scenes.CONFIGS[2].extra), 160, 90, 2),
     "depth1": (scenes.build_config2, scenes.Config("d1", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 1.2, 0.0), max_depth=1, extra=scenes.CONFIGS[2].extra), 96, 54, 2),
+    "depth0": (scenes.build_config2, scenes.Config("d0", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 1.2, 0.0), max_depth=0, extra=scenes.CONFIGS[2].extra), 64, 40, 2),
     "empty_scene": (lambda b: b.rebuild_tlas(), scenes.CONFIGS[1], 64, 40, 2),
     "rotated_scaled_instances": (scenes.build_rotated_instances_scene, scenes.Config("rot", 0, 0, 0, (0.4, 1.6, 4.6), (0.0, 0.8, 0.0)), 176, 112, 2),
 }
