@@ -160,6 +160,24 @@ hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int c
     C.flush(counters);
 }
 
+template <int FEAT>
+__global__ void __launch_bounds__(256, 4)
+hrt_wf_walkw_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained)
+{
+    int own = -1;
+    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    wf_walkw_shadow_wave<FEAT>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own);
+}
+
+template <int FEAT>
+__global__ void __launch_bounds__(256, 4)
+hrt_wf_walkw_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained)
+{
+    int own = -1;
+    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    wf_walkw_closest_wave<FEAT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own);
+}
+
 template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256)
 hrt_wf_finish_kernel(TracerPackedT<FEAT> tr, FrameK k, WfBuffers W, int vsel, int depth)
@@ -241,7 +259,7 @@ struct DeviceState {
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
-    void* packed[5] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
+    void* packed[6] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
     DPacked dpacked{};
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
@@ -249,6 +267,7 @@ struct DeviceState {
     // streamed path-trace workspace
     float* wf_mem = nullptr; size_t wf_bytes = 0;
     int* wf_cnt = nullptr; size_t wf_cnt_ints = 0;
+    int* wf_ovf = nullptr;                     // wide walker stack overflow area (allocated on first use)
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
     int64_t nPix = 0;
     DGBuffer gb{};
@@ -268,6 +287,7 @@ struct hrt_ctx {
     bool scene_ready = false;
     bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
     int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
+    int wide_depth = 0;                        // > 0: the 4-wide collapse exists; stack bound of the wide walker = 3 * wide_depth + 2
     int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
     bool small_scene = false;                  // <= kSmallSceneNodes BVH nodes: the walk is ALU-bound and L1-resident -> megakernel
     int width = 0, height = 0;
@@ -364,13 +384,15 @@ void free_workspace(DeviceState& d)
 {
     if (d.wf_mem) (void)hipFree(d.wf_mem);
     if (d.wf_cnt) (void)hipFree(d.wf_cnt);
+    if (d.wf_ovf) (void)hipFree(d.wf_ovf);
+    d.wf_ovf = nullptr;
     d.wf_mem = nullptr; d.wf_cnt = nullptr; d.wf_bytes = 0; d.wf_cnt_ints = 0;
 }
 
 void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
-    for (int i = 0; i < 5; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
+    for (int i = 0; i < 6; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -383,6 +405,9 @@ struct PackedHost {
     std::vector<NodeQ> tlas, blas, flat;     // flat: the TLAS leaves in walk order (TracerFlat)
     std::vector<FInst> finst;
     std::vector<FTri> ftri;
+    std::vector<WNode> wide;  // 4-wide collapse of the TLAS and of every BLAS range (wide walker)
+    int wide_tlas_root = kWNone;
+    int wide_depth = 0;       // wide levels of the TLAS + of the deepest BLAS (stack bound of the wide walker); 0: not built
     int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
@@ -606,6 +631,85 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         o.v1 = mkf4(b.X, b.Y, b.Z, bits_f(mi));
         o.v2 = mkf4(c.X, c.Y, c.Z, bits_f(fl));
     }
+    // ---- 4-wide collapse for the wide walker: every inner node takes its grandchildren (children where a child is a leaf),
+    // kept in walk order; nodes are numbered depth-first so a subtree is contiguous.  Returns the reference of the range's root.
+    int wideDepthMax = 0;
+    auto collapse = [&](const std::vector<NodeQ>& nodes, int64_t rootIdx, int& depthOut) -> int {
+        auto cnt_of = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, nodes[(size_t)i].hi.w) >> 28); };
+        auto left_of = [&](int64_t i) { return (int64_t)(__builtin_bit_cast(int, nodes[(size_t)i].lo.w) & kEnd); };
+        auto skip_of = [&](int64_t i) { return (int64_t)(__builtin_bit_cast(int, nodes[(size_t)i].hi.w) & kEnd); };
+        depthOut = 0;
+        if (cnt_of(rootIdx) > 0) return ~(int)rootIdx;                 // the whole tree is one leaf
+        struct Job { int64_t node; int wide; int depth; };
+        std::vector<Job> jobs;
+        const int rootWide = (int)out.wide.size();
+        out.wide.emplace_back();
+        jobs.push_back({rootIdx, rootWide, 1});
+        while (!jobs.empty())
+        {
+            const Job jb = jobs.back(); jobs.pop_back();
+            depthOut = std::max(depthOut, jb.depth);
+            int64_t kids[4]; int nk = 0;
+            const int64_t l = left_of(jb.node);
+            if (l == kEnd) { out.wide[(size_t)jb.wide] = WNode{}; out.wide[(size_t)jb.wide].ref = int4{kWNone, kWNone, kWNone, kWNone}; continue; }   // inner node without children
+            const int64_t r = skip_of(l);
+            for (int64_t c : {l, r})
+            {
+                if (c == kEnd) continue;
+                const int64_t cl = cnt_of(c) > 0 ? kEnd : left_of(c);
+                if (cnt_of(c) > 0 || cl == kEnd) { kids[nk++] = c; continue; }
+                kids[nk++] = cl;
+                const int64_t cr = skip_of(cl);
+                if (cr != kEnd && cr != skip_of(c)) kids[nk++] = cr;       // right grandchild: the left one's skip link, unless that already leaves the subtree of c
+            }
+            WNode w; std::memset(&w, 0, sizeof w);
+            float* lo[3] = {&w.lox.x, &w.loy.x, &w.loz.x}; float* hi[3] = {&w.hix.x, &w.hiy.x, &w.hiz.x};
+            int refs[4] = {kWNone, kWNone, kWNone, kWNone};
+            std::vector<Job> sub;
+            for (int j = 0; j < nk; j++)
+            {
+                const NodeQ& q = nodes[(size_t)kids[j]];
+                lo[0][j] = q.lo.x; lo[1][j] = q.lo.y; lo[2][j] = q.lo.z; hi[0][j] = q.hi.x; hi[1][j] = q.hi.y; hi[2][j] = q.hi.z;
+                if (cnt_of(kids[j]) > 0) refs[j] = ~(int)kids[j];
+                else { refs[j] = (int)out.wide.size(); out.wide.emplace_back(); sub.push_back({kids[j], refs[j], jb.depth + 1}); }
+            }
+            w.ref = int4{refs[0], refs[1], refs[2], refs[3]};
+            out.wide[(size_t)jb.wide] = w;
+            for (size_t k = sub.size(); k-- > 0;) jobs.push_back(sub[k]);          // first child's subtree gets the next indices
+        }
+        return rootWide;
+    };
+    out.wide.clear();
+    if (out.ok && reachableT > 0 && getenv("HRT_WIDE") && atoi(getenv("HRT_WIDE")) > 0)        // experiment, off by default
+    {
+        int dT = 0;
+        out.wide_tlas_root = collapse(out.tlas, 0, dT);
+        int dB = 0;
+        bool fits = true;
+        for (int64_t i = 0; i < nTI; i++)
+        {
+            FInst& f = out.finst[(size_t)i];
+            if (__builtin_bit_cast(int, f.a.w) & FI_FAST_SPHERE) continue;
+            const int root = __builtin_bit_cast(int, f.c.x), end = __builtin_bit_cast(int, f.c.y);
+            int d = 0, ref = kWNone;
+            if (root < end)
+            {   // several leaf slots may share one BLAS range: collapse it once
+                bool found = false;
+                for (int64_t k = 0; k < i && !found; k++)
+                    if (!(__builtin_bit_cast(int, out.finst[(size_t)k].a.w) & FI_FAST_SPHERE) && __builtin_bit_cast(int, out.finst[(size_t)k].c.x) == root && i - k < 64)
+                    { ref = __builtin_bit_cast(int, out.finst[(size_t)k].c.w); found = true; }
+                if (!found) ref = collapse(out.blas, root, d);
+            }
+            dB = std::max(dB, d);
+            f.c.w = bits_f(ref);
+            if (out.wide.size() > (size_t)0x3FFFFFFF) fits = false;
+        }
+        out.wide_depth = dT + dB;
+        if (!fits) { out.wide.clear(); out.wide_depth = 0; }
+    }
+    if (out.wide.empty()) { out.wide.assign(1, WNode{}); out.wide_depth = 0; }
+    (void)wideDepthMax;
+
     // TracerFlat: the reachable TLAS leaves in walk order, for scenes made of fast-sphere instances only
     out.flat.assign(1, NodeQ{});
     if (out.ok && out.feat == 0 && reachableT > 0)
@@ -691,6 +795,7 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nR
     W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap); W.accum = take(3, nOrd);
     W.cntA = d.wf_cnt; W.cntS = d.wf_cnt + (size_t)(maxDepth + 1) * (size_t)nRanges;
     W.grab = d.wf_cnt + (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
+    W.ovf = d.wf_ovf;
     W.nRanges = nRanges;
     return HRT_OK;
 }
@@ -730,6 +835,16 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
     // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
+    // wide walker (experiment, HRT_WIDE=1 at upload and render time; production frames only): needs the collapsed trees and a
+    // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
+    static const int wideEnv = getenv("HRT_WIDE") ? atoi(getenv("HRT_WIDE")) : 0;
+    const bool wide = wideEnv > 0 && !count && PackedFeat<TR>::value >= 0 && c->wide_depth > 0 && c->wide_depth <= kWideMaxDepth;
+    if (wide && !d.wf_ovf)
+    {
+        void* v = nullptr;
+        HIPCHK(c, hipMalloc(&v, (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));
+        d.wf_ovf = (int*)v; W.ovf = d.wf_ovf;
+    }
     for (int b0 = 0; b0 < spp; b0 += (int)sb)
     {
         if (k.maxDepth > 0) HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
@@ -741,7 +856,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         for (int depth = 0; depth < k.maxDepth; depth++)
         {
             const int vsel = depth & 1;
-            const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0) ? 1 : 0;
+            const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0 || wide) ? 1 : 0;      // the wide walker's overflow area is sized for the persistent grid
             if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             if constexpr (PackedFeat<TR>::value >= 0)
@@ -752,6 +867,12 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                }
+                else if (wide)
+                {
+                    hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained);
+                    hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
                 else
                 {
@@ -922,6 +1043,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->packed_feat = (ph.feat & 2) ? 3 : (ph.feat & 1);
     c->small_scene = (s->n_tlasNodes + s->n_blasNodes) <= kSmallSceneNodes;
     c->flat_leaves = ph.n_flat;
+    c->wide_depth = ph.wide_depth;
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
     for (DeviceState& d : c->dev)
@@ -948,10 +1070,10 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
         // device-private repack (TracerPacked)
-        const void* psrc[5] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data()};
-        const size_t pbytes[5] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
-                                  ph.flat.size() * sizeof(NodeQ)};
-        for (int i = 0; i < 5; i++)
+        const void* psrc[6] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), ph.wide.data()};
+        const size_t pbytes[6] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
+                                  ph.flat.size() * sizeof(NodeQ), ph.wide.size() * sizeof(WNode)};
+        for (int i = 0; i < 6; i++)
         {
             HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
@@ -959,6 +1081,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
         d.dpacked.nTlas = (int)ph.tlas.size();
+        d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;

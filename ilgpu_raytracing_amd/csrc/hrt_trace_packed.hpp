@@ -33,6 +33,14 @@ struct NodeQ { float4 lo, hi; };            // lo.w = bits(left | first), hi.w =
 struct FInst { float4 a, b, c; };           // a.w = bits(flags), b.w = bits(index); see hrt_runtime.hip pack_scene()
 struct FTri  { float4 v0, v1, v2; };        // v0.w = bits(triIndex), v1.w = bits(matIndex), v2.w = bits(flags)
 
+// WNode 128 B (one cache line): the binary tree collapsed two levels at a time.  Up to 4 children in WALK ORDER with their
+// exact boxes, child-major per coordinate (lox = lo.x of children 0..3, ...).  ref[j] >= 0: index of the child's WNode;
+// ref[j] < 0 and != kWNone: ~ref[j] is the index of the child's LEAF record in the binary NodeQ array (first, count and the box
+// again); kWNone: no child.  Inner nodes only accelerate, so how they are grouped is free as long as leaves are
+// met in walk order and take their own exact test at entry.
+struct WNode { float4 lox, loy, loz, hix, hiy, hiz; int4 ref; int4 pad; };
+constexpr int kWNone = (int)0x80000000;
+
 enum { FI_FAST_SPHERE = 1, FI_IDENTITY = 2, FI_SPHERESET = 4 };
 enum { FT_TEXTURED = 1, FT_TWOSIDED = 2 };  // FT_TEXTURED: usable diffuse or alpha map, or AlphaCutoff > 1 (rejects alpha = 1)
 
@@ -42,6 +50,8 @@ struct DPacked {
     const NodeQ* blas;       // indexed like blasNodes
     const FTri* ftri;        // indexed like triPrimIdx
     int nTlas;               // records in tlas (>= 1)
+    const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
+    int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514
@@ -208,14 +218,24 @@ struct TracerPackedT {
     template <bool COUNT>
     HRT_D bool closest(const Ray& wray_in, Hit& best, Cnt<COUNT>& C) const
     {
-        __shared__ float park_mem[kGeneral ? 9 : 1][256];
-        RayPark park; park.sh = park_mem;
+        float bestT, bestTObj; int bestSlot, bestPrim;
+        closest_raw<COUNT>(wray_in, bestT, bestTObj, bestSlot, bestPrim, C);
+        return finish_hit(wray_in, bestT, bestTObj, bestSlot, bestPrim, best);
+    }
+    // the walk alone: raw winner (world t, object-space t, TLAS leaf slot, primitive), t = 1e30 on a miss
+    // EXT: the caller lends its own LDS ray park (kernels that already have one must not pay for a second)
+    template <bool COUNT, bool EXT = false>
+    HRT_D void closest_raw(const Ray& wray_in, float& bestT, float& bestTObj, int& bestSlot, int& bestPrim, Cnt<COUNT>& C, float (*ext)[256] = nullptr) const
+    {
+        RayPark park;
+        if constexpr (EXT) park.sh = ext;
+        else { __shared__ float park_mem[kGeneral ? 9 : 1][256]; park.sh = park_mem; }
         Ray wray = wray_in;
         C.inc(C_RAYS_CLOSEST);
-        float bestT = 1e30f;        // closestT (world)
-        float bestTObj = 0.f;       // object-space t of the winner (== bestT * scale)
-        int bestSlot = -1;          // TLAS leaf slot (index into finst / tlasInstanceIndices)
-        int bestPrim = -1;          // sphere index, or BLAS leaf slot of the triangle
+        bestT = 1e30f;              // closestT (world)
+        bestTObj = 0.f;             // object-space t of the winner (== bestT * scale)
+        bestSlot = -1;              // TLAS leaf slot (index into finst / tlasInstanceIndices)
+        bestPrim = -1;              // sphere index, or BLAS leaf slot of the triangle
         int cur = 0;
         for (;;)
         {
@@ -231,7 +251,7 @@ struct TracerPackedT {
                 if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
                 cur = wbits(n.lo) & kEnd;
             }
-            if (lcount == 0) break;
+            if (lcount == 0) return;
             for (int i = lfirst; i < lfirst + lcount; i++)
             {
                 FInst f = P.finst[i];
@@ -273,8 +293,6 @@ struct TracerPackedT {
             }
             cur = lskip;
         }
-
-        return finish_hit(wray, bestT, bestTObj, bestSlot, bestPrim, best);
     }
 
     // ---- shade the winner of a walk once (normal :534-535/:556, albedo :146-159/:210-223, world normal :71).
@@ -422,10 +440,13 @@ struct TracerPackedT {
 
     // ---------------- ShadowOcclusion (:89-121)
     template <bool COUNT>
-    HRT_D bool occluded(const Ray& wray_in, float tMaxWorld, Cnt<COUNT>& C) const
+    HRT_D bool occluded(const Ray& wray_in, float tMaxWorld, Cnt<COUNT>& C) const { return occluded_ext<COUNT, false>(wray_in, tMaxWorld, C, nullptr); }
+    template <bool COUNT, bool EXT>
+    HRT_D bool occluded_ext(const Ray& wray_in, float tMaxWorld, Cnt<COUNT>& C, float (*ext)[256]) const
     {
-        __shared__ float park_mem[kGeneral ? 9 : 1][256];
-        RayPark park; park.sh = park_mem;
+        RayPark park;
+        if constexpr (EXT) park.sh = ext;
+        else { __shared__ float park_mem[kGeneral ? 9 : 1][256]; park.sh = park_mem; }
         Ray wray = wray_in;
         C.inc(C_RAYS_SHADOW);
         int cur = 0;
