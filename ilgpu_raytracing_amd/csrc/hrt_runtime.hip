@@ -252,6 +252,8 @@ struct DeviceState {
     int device_id = -1;
     int n_cu = 256;                            // compute units (MI355X: 256)
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;             // shadow walks run beside the closest-hit walks of the same bounce
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     static constexpr int kRing = 128;          // frames that may be in flight between two syncs
     hipEvent_t ev[kRing][4] = {};
     int ring_head = 0;                         // frames enqueued since the last synchronize
@@ -838,6 +840,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     // wide walker (experiment, HRT_WIDE=1 at upload and render time; production frames only): needs the collapsed trees and a
     // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
     static const int wideEnv = getenv("HRT_WIDE") ? atoi(getenv("HRT_WIDE")) : 0;
+    static const bool forkShadow = getenv("HRT_NO_FORK") == nullptr;       // A/B knob
+    static const bool forkStatic = getenv("HRT_FORK_STATIC") != nullptr;   // A/B knob
     const bool wide = wideEnv > 0 && !count && PackedFeat<TR>::value >= 0 && c->wide_depth > 0 && c->wide_depth <= kWideMaxDepth;
     if (wide && !d.wf_ovf)
     {
@@ -872,6 +876,18 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 {
                     hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained);
                     hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                }
+                else if ((chained || forkStatic) && forkShadow)
+                {   // the two walks of a bounce are independent (shadow requests vs bounce rays) and both are persistent
+                    // launches that end in a drain: on two streams the second one's workgroups move into the wave slots
+                    // the first one's drain frees, instead of waiting for its last ray
+                    HIPCHK(c, hipEventRecord(d.evFork, d.stream));
+                    HIPCHK(c, hipStreamWaitEvent(d.stream2, d.evFork, 0));
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
+                    HIPCHK(c, hipEventRecord(d.evJoin, d.stream2));
+                    HIPCHK(c, hipStreamWaitEvent(d.stream, d.evJoin, 0));
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
                 else
@@ -938,6 +954,9 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
         hipError_t err = hipSetDevice(d.device_id);
         if (err == hipSuccess) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d.device_id) == hipSuccess && cu > 0) d.n_cu = cu; }
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming);
         for (int f = 0; f < DeviceState::kRing && err == hipSuccess; f++)
             for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[f][k]);
         if (err == hipSuccess) { void* p = nullptr; err = hipMalloc(&p, 20 * sizeof(unsigned long long)); d.counters = (unsigned long long*)p; }
@@ -975,6 +994,9 @@ void hrt_destroy(hrt_ctx* c)
         if (d.counters) (void)hipFree(d.counters);
         for (int f = 0; f < DeviceState::kRing; f++)
             for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
+        if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
+        if (d.evFork) (void)hipEventDestroy(d.evFork);
+        if (d.evJoin) (void)hipEventDestroy(d.evJoin);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete c;
