@@ -29,7 +29,7 @@ using namespace hrt;
 // contiguous band of tiles so each private 4 MiB L2 caches one region of the BVH instead
 // of all of it (bijective form of the T1 remap, cdna_hip_programming.md).
 // ---------------------------------------------------------------------------------------
-struct TileMap { int tilesX, tilesY, nTiles; };
+struct TileMap { int tilesX, tilesY, nTiles, wpb; };      // wpb: waves (8x8 pixel tiles) per workgroup, side by side
 
 __device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, int& x, int& y)
 {
@@ -39,7 +39,7 @@ __device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, i
     int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
     int ty = tile / tm.tilesX, tx = tile - ty * tm.tilesX;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    x = tx * 32 + wave * 8 + (lane & 7);
+    x = (tx * tm.wpb + wave) * 8 + (lane & 7);
     y = k.row_begin + (ty * k.strip_n + k.strip_i) * 8 + (lane >> 3);   // 8-row strips dealt round-robin over tiles
     return x < k.width && y < k.row_end;
 }
@@ -813,7 +813,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     if (tm.nTiles <= 0) return HRT_OK;
     if (mega || k.maxDepth > 64)
     {
-        const dim3 grid(tm.nTiles), block(256);
+        const dim3 grid(tm.nTiles), block(64 * tm.wpb);
         if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
         else       hipLaunchKernelGGL((hrt_path_trace_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
         HIPCHK(c, hipGetLastError());
@@ -1198,9 +1198,13 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         k.rngLockNoise = p->rngLockNoise; k.spp = p->spp; k.maxDepth = p->maxDepth;
         return k;
     };
+    // pixel kernels: waves per workgroup.  One wave per workgroup gives the dispatcher the finest grain: the launch ends when
+    // the last 8x8 tile ends instead of the last 32x8 tile (matters most when a rank renders 1/8 of the image)
+    static const int ptWaves = getenv("HRT_PT_BLOCK") ? std::max(1, std::min(4, atoi(getenv("HRT_PT_BLOCK")) / 64)) : 4;
     auto tile_map = [&](const DeviceState& d) {
         TileMap tm;
-        tm.tilesX = (p->width + 31) / 32;
+        tm.wpb = ptWaves;
+        tm.tilesX = (p->width + 8 * ptWaves - 1) / (8 * ptWaves);
         tm.tilesY = d.n_strips;
         tm.nTiles = tm.tilesX * tm.tilesY;
         return tm;
@@ -1255,7 +1259,7 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         HIPCHK(c, hipEventRecord(ev[0], d.stream));
         if (tm.nTiles > 0 && !(flags & HRT_FLAG_SKIP_PRIMARY))
         {
-            const dim3 grid(tm.nTiles), block(256);
+            const dim3 grid(tm.nTiles), block(64 * tm.wpb);
             int rcs = with_tracer(d, [&](auto tr) -> int {
                 using TR = decltype(tr);
                 if (count) hipLaunchKernelGGL((hrt_primary_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
