@@ -4,7 +4,7 @@ from ilgpu_raytracing_amd import _types as T, scenes, engine
 r = engine.RTRenderer([0]); s = engine.Scene(); scenes.build(2, s); r.commit(s)
 cfg = scenes.CONFIGS[2]
 p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction)
-for n in (1, 8):
+for n in (1, 2, 4, 8):
     r.render_params(p, None, strips=(n, 0)); 
     for rep in range(2):
         t0 = time.perf_counter()
