@@ -75,3 +75,31 @@ def test_fails_loudly_without_gpu(hrt_lib):
 
 def test_version_string(hrt_lib):
     assert b"gfx950" in hrt_lib.hrt_version()
+
+
+def _build_c_example(tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "ilgpu_raytracing_amd", "csrc")
+    exe = str(tmp_path / "hrt_bench")
+    subprocess.check_call(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", INC, os.path.join(root, "examples", "hrt_bench.c"), "-o", exe,
+                           "-L", csrc, "-lhip_raytrace", "-Wl,-rpath," + csrc, "-lm"])
+    return exe
+
+
+def test_plain_c_host_builds_and_fails_loudly_without_gpu(hrt_lib, tmp_path):
+    """examples/hrt_bench.c: the boundary used from C11 with nothing but the two headers and -lhip_raytrace."""
+    exe = _build_c_example(tmp_path)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_plain_c_host_renders")
+    out = subprocess.run([exe, "64", "48", "1", "1"], capture_output=True, text=True)
+    assert out.returncode == 1 and "no HIP device" in out.stderr and "no CPU path" in out.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_host_renders(hrt_lib, tmp_path):
+    import json
+    exe = _build_c_example(tmp_path)
+    runs = [json.loads(subprocess.run([exe, "320", "180", "2", "3"], capture_output=True, text=True, check=True).stdout) for _ in range(2)]
+    assert runs[0]["color_checksum"] == runs[1]["color_checksum"] and runs[0]["rays_per_frame"] == runs[1]["rays_per_frame"]
+    assert runs[0]["host"] == "C" and runs[0]["frames"] == 3 and runs[0]["mrays_per_s"] > 0 and runs[0]["rays_per_frame"] > 320 * 180
