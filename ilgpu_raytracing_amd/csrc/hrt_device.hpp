@@ -651,14 +651,29 @@ HRT_D Frame make_frame(F3 n)
     f.b = cross(n, f.t);
     return f;
 }
+// IEEE square root for arguments that are +0 or normal numbers >= 2^-96 (finite): the same v_sqrt_f32 + two one-ulp
+// corrections hipcc emits for sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt), minus the rescaling of tiny arguments and
+// the class test for infinities -- 7 of its 17 instructions.  tests/test_math_gpu.py compares it with hrt_sqrt over every
+// argument the sampler below can produce and over [1e-20, 1e20].
+HRT_D float sqrt_normal_range(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sDn = __int_as_float(__float_as_int(s) - 1), sUp = __int_as_float(__float_as_int(s) + 1);
+    const float rDn = __builtin_fmaf(-sDn, s, x), rUp = __builtin_fmaf(-sUp, s, x);
+    float r = (rDn <= 0.f) ? sDn : s;
+    r = (rUp > 0.f) ? sUp : r;
+    return (x == 0.f) ? x : r;
+}
 HRT_D F3 sample_hemisphere_cosine(const Frame& f, Rng& rng)
 {
-    float r1 = rng.next_f(), r2 = rng.next_f();
+    float r1 = rng.next_f(), r2 = rng.next_f();          // k / 2^24: r2 is 0 or >= 2^-24, 1 - r2 is >= 2^-24
     float phi = 2.f * kPI * r1;
-    float cosTheta = hrt_sqrt(1.f - r2);
-    float sinTheta = hrt_sqrt(r2);
-    float x = hrt_cos(phi) * sinTheta;
-    float y = hrt_sin(phi) * sinTheta;
+    float cosTheta = sqrt_normal_range(1.f - r2);
+    float sinTheta = sqrt_normal_range(r2);
+    float sn, cs;
+    hrt_sincos(phi, &sn, &cs);                   // == hrt_sin(phi), hrt_cos(phi); both polynomials once, no divergent branch
+    float x = cs * sinTheta;
+    float y = sn * sinTheta;
     float z = cosTheta;
     F3 v = f.t * x + f.b * y + f.n * z;
     return normalize(v);

@@ -237,6 +237,9 @@ __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float
     case 14: r = 1.0f / a; break;    case 15: r = a / b; break;
     case 16: r = a * b + a; break;   // must NOT be contracted
     case 17: r = hrt_log(a); break;  case 18: r = hrt_exp(a); break;  case 19: r = hrt_pow(a, b); break;
+    case 20: { float s, c; hrt_sincos(a, &s, &c); r = s; } break;
+    case 21: { float s, c; hrt_sincos(a, &s, &c); r = c; } break;
+    case 22: r = sqrt_normal_range(a); break;
     }
     out[i] = r;
 }

@@ -130,6 +130,28 @@ HRT_HD float hrt_cos(float xin)
     return (sign < 0.0f) ? -r : r;
 }
 
+/* hrt_sin(x) and hrt_cos(x) of the same argument in one go: the argument reduction and BOTH polynomials are evaluated once,
+ * without a branch, and handed to sine / cosine by quadrant -- each result is the very expression hrt_sin / hrt_cos return
+ * (tests/test_math_gpu.py compares them bit for bit).  For device code that needs the pair (cosine-hemisphere sampling). */
+HRT_HD void hrt_sincos(float xin, float* s, float* c)
+{
+    float x = (xin < 0.0f) ? -xin : xin;
+    int j = (int)(HRT_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    int sneg = xin < 0.0f, cneg = 0;
+    if (j > 3) { sneg = !sneg; cneg = !cneg; j -= 4; }
+    if (j > 1) cneg = !cneg;
+    x = ((x - y * HRT_DP1) - y * HRT_DP2) - y * HRT_DP3;
+    float z = x * x;
+    float sp = hrt__sin_poly(x, z), cp = hrt__cos_poly(z);
+    int sw = (j == 1 || j == 2);
+    float rs = sw ? cp : sp, rc = sw ? sp : cp;
+    *s = sneg ? -rs : rs;
+    *c = cneg ? -rc : rc;
+}
+
 HRT_HD float hrt_tan(float xin)
 {
     float sign = 1.0f;

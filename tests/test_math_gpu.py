@@ -46,3 +46,29 @@ def test_device_code_is_not_contracted(renderer):
     got = renderer.math_probe(16, x, y)                                    # a*b + a
     want = (x * y).astype(np.float32) + x
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_fused_sincos_equals_sin_and_cos(orc, renderer):
+    """hrt_sincos (device helper of the cosine-hemisphere sampler) returns the bits of hrt_sin and hrt_cos: every phi = 2*pi*k/2^24
+    the sampler can produce from a 24-bit RNG draw on a stride, plus negative and large arguments."""
+    k = np.arange(0, 1 << 24, 7, dtype=np.int64)
+    phi = (np.float32(2.0) * np.float32(3.14159265358979323846)) * (k.astype(np.float32) * np.float32(1.0 / 16777216.0))
+    rng = np.random.default_rng(14)
+    x = np.concatenate([phi.astype(np.float32), rng.uniform(-50, 50, 200000).astype(np.float32), np.array([0.0, -0.0], np.float32)])
+    s_ref, c_ref = orc.math_eval("sin", x), orc.math_eval("cos", x)
+    s_got, c_got = renderer.math_probe(20, x), renderer.math_probe(21, x)
+    assert np.array_equal(s_ref.view(np.uint32), s_got.view(np.uint32))
+    assert np.array_equal(c_ref.view(np.uint32), c_got.view(np.uint32))
+
+
+def test_sqrt_normal_range_equals_ieee_sqrt(orc, renderer):
+    """The trimmed square root of the hemisphere sampler against the IEEE one: EVERY k / 2^24 (both sampler arguments r2 and
+    1 - r2 are of that form) and a wide sample of its stated domain."""
+    k = np.arange(0, 1 << 24, dtype=np.float32) * np.float32(1.0 / 16777216.0)
+    rng = np.random.default_rng(15)
+    wide = (10.0 ** rng.uniform(-20, 20, 2000000)).astype(np.float32)
+    edge = np.array([0.0, 2.0 ** -96, 2.0 ** -24, 1.0, 1.0 - 2.0 ** -24, 4.0, 1e-20, 3.0e38], np.float32)
+    for x in (k, np.float32(1.0) - k, wide, edge):
+        a = orc.math_eval("sqrt", x)
+        b = renderer.math_probe(22, x)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
