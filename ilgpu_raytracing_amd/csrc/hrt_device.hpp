@@ -830,22 +830,36 @@ HRT_D void primary_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, int 
 
 // PathTraceKernel (RTRay.cs:203-325), one pixel per lane, restructured so that each bounce
 // has one shadow-ray site and one closest-hit site shared by all material branches.
-template <class TR, bool COUNT>
+// SPLIT (small tiles, see SplitK): the lane runs only samples [sk.sBegin, sk.sEnd) of its pixel and hands per-sample radiance
+// and its last reservoir to split_resolve_pixel instead of accumulating and storing itself.
+struct SplitK {
+    hrt_float3* li;          // [spp][nPix]: SafeColor(Li) of every sample
+    float* stage;            // [nGroups][12][nPix]: L.xyz wi.xyz pdf w wSum m lightId flag of the group's last reservoir
+    int sBegin, sEnd, group, nGroups;
+};
+template <class TR, bool COUNT, bool SPLIT = false>
 HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb,
-                            const DReservoir& resPrev, const DReservoir& resCur, int64_t nPix, int index, Cnt<COUNT>& C)
+                            const DReservoir& resPrev, const DReservoir& resCur, int64_t nPix, int index, Cnt<COUNT>& C, const SplitK* sk = nullptr)
 {
-    if (index == 0 && fb.cameraId) fb.cameraId[0] = k.debugCamSeq;
+    if (index == 0 && fb.cameraId && (!SPLIT || sk->group == 0)) fb.cameraId[0] = k.debugCamSeq;
 
     int px = index % hrt_imax(1, k.width), py = index / hrt_imax(1, k.width);
-    const int spp = hrt_imax(1, k.spp);
+    const int sppAll = hrt_imax(1, k.spp);
+    const int sFirst = SPLIT ? sk->sBegin : 0;
+    const int spp = SPLIT ? sk->sEnd : sppAll;           // end of this lane's sample range
     F3 Lframe = mk3(0.f, 0.f, 0.f);
+    auto add_sample = [&](int sIdx, F3 c) {              // Lframe += SafeColor(Li), RTRay.cs:320 -- or hand the term to the resolve
+        if (SPLIT) sk->li[(size_t)sIdx * (size_t)nPix + (size_t)index] = to3(c);
+        else Lframe = Lframe + c;
+    };
 
     const int hitMask = gb.hitMask[index];
 
     if (hitMask == 0)
     {
         F3 c = safe_color(sky(k, primary_ray(k, px, py).d));
-        for (int s = 0; s < spp; s++) Lframe = Lframe + c;     // :214-219, same value every sample
+        for (int s = sFirst; s < spp; s++) add_sample(s, c);     // :214-219, same value every sample
+        if (SPLIT) sk->stage[(size_t)sk->group * 12 * (size_t)nPix + 11 * (size_t)nPix + (size_t)index] = 0.f;      // no reservoir from this group
     }
     else
     {
@@ -868,12 +882,12 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         // Lanes do not wait for each other at sample boundaries: every lane runs its own (sample, depth)
         // cursor through one flat bounce loop, so a lane whose path ended starts its next sample while its
         // neighbours are still bouncing.  Per-pixel order is untouched (samples of a pixel stay sequential).
-        int s = 0, depth = 0;
-        Rng rng = rng_for_sample(sb, 0u);
+        int s = sFirst, depth = 0;
+        Rng rng = rng_for_sample(sb, (uint32_t)sFirst);
         bool wroteReservoir = false;            // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
         start_vertex();
         F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);
-        if (k.maxDepth <= 0) { for (; s < spp; s++) Lframe = Lframe + safe_color(Li); }
+        if (k.maxDepth <= 0) { for (; s < spp; s++) add_sample(s, safe_color(Li)); }
 
         while (s < spp)
         {
@@ -982,7 +996,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             }
             if (ended)
             {
-                Lframe = Lframe + safe_color(Li);                  // :320
+                add_sample(s, safe_color(Li));                     // :320
                 s++;
                 if (s < spp)
                 {   // next sample starts again from the G-buffer vertex (:212-231)
@@ -994,14 +1008,52 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 }
             }
         }
-        if (haveRes)
+        if (SPLIT)
+        {   // this group's last reservoir (or "none"): split_resolve_pixel keeps the one of the last group that has one
+            float* st = sk->stage + (size_t)sk->group * 12 * (size_t)nPix + (size_t)index;
+            const size_t P = (size_t)nPix;
+            st[11 * P] = haveRes ? 1.f : 0.f;
+            if (haveRes)
+            {
+                st[0] = lastRes.L.x; st[P] = lastRes.L.y; st[2 * P] = lastRes.L.z; st[3 * P] = lastRes.wi.x; st[4 * P] = lastRes.wi.y; st[5 * P] = lastRes.wi.z;
+                st[6 * P] = lastRes.pdf; st[7 * P] = lastRes.w; st[8 * P] = lastRes.wSum; st[9 * P] = __int_as_float(lastRes.m); st[10 * P] = __int_as_float(lastRes.lightId);
+            }
+        }
+        else if (haveRes)
         {
             resCur.L[index] = to3(lastRes.L); resCur.wi[index] = to3(lastRes.wi); resCur.pdf[index] = lastRes.pdf;
             resCur.w[index] = lastRes.w; resCur.wSum[index] = lastRes.wSum; resCur.lightId[index] = lastRes.lightId;
             resCur.m[index] = lastRes.m;
         }
     }
+    if (SPLIT) return;
 
+    F3 Lout = Lframe * (1.0f / (float)sppAll);
+    if (fb.radiance) fb.radiance[index] = to3(Lout);
+    fb.color[index] = pack_rgba8(Lout);
+    fb.depth[index] = cam_distance(k, ld3(&gb.worldPos[index]));
+    fb.objectId[index] = gb.objId[index];
+}
+
+// second half of a SPLIT frame: ordered sample sum (:320-324), reservoir of the last sample that reached a diffuse vertex
+HRT_D void split_resolve_pixel(const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb, const DReservoir& resCur, int64_t nPix, int index,
+                               const hrt_float3* li, const float* stage, int nGroups)
+{
+    const int spp = hrt_imax(1, k.spp);
+    F3 Lframe = mk3(0.f, 0.f, 0.f);
+    for (int s = 0; s < spp; s++) Lframe = Lframe + ld3(&li[(size_t)s * (size_t)nPix + (size_t)index]);
+    const size_t P = (size_t)nPix;
+    for (int g = nGroups - 1; g >= 0; g--)
+    {
+        const float* st = stage + (size_t)g * 12 * P + (size_t)index;
+        if (st[11 * P] != 0.f)
+        {
+            resCur.L[index] = to3(mk3(st[0], st[P], st[2 * P])); resCur.wi[index] = to3(mk3(st[3 * P], st[4 * P], st[5 * P]));
+            resCur.pdf[index] = st[6 * P]; resCur.w[index] = st[7 * P]; resCur.wSum[index] = st[8 * P];
+            resCur.lightId[index] = __float_as_int(st[10 * P]); resCur.m[index] = __float_as_int(st[9 * P]);
+            break;
+        }
+    }
     F3 Lout = Lframe * (1.0f / (float)spp);
     if (fb.radiance) fb.radiance[index] = to3(Lout);
     fb.color[index] = pack_rgba8(Lout);

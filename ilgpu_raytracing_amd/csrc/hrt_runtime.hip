@@ -31,9 +31,8 @@ using namespace hrt;
 // ---------------------------------------------------------------------------------------
 struct TileMap { int tilesX, tilesY, nTiles, wpb; };      // wpb: waves (8x8 pixel tiles) per workgroup, side by side
 
-__device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, int& x, int& y)
+__device__ __forceinline__ bool tile_pixel(const TileMap& tm, const FrameK& k, int& x, int& y, int orig)
 {
-    int orig = blockIdx.x;
     int q = tm.nTiles >> 3, r = tm.nTiles & 7;
     int xcd = orig & 7, seq = orig >> 3;
     int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
@@ -52,7 +51,7 @@ hrt_primary_kernel(TR tr, FrameK k, DGBuffer gb, TileMap tm, unsigned long long*
 {
     Cnt<COUNT> C;
     int x, y;
-    if (tile_pixel(tm, k, x, y)) primary_pixel<TR, COUNT>(tr, k, gb, y * k.width + x, C);
+    if (tile_pixel(tm, k, x, y, blockIdx.x)) primary_pixel<TR, COUNT>(tr, k, gb, y * k.width + x, C);
     C.flush(counters);
 }
 
@@ -66,8 +65,33 @@ hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir 
 {
     Cnt<COUNT> C;
     int x, y;
-    if (tile_pixel(tm, k, x, y)) path_trace_pixel<TR, COUNT>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
+    if (tile_pixel(tm, k, x, y, blockIdx.x)) path_trace_pixel<TR, COUNT>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
     C.flush(counters);
+}
+
+// Small tiles (a rank's share of a frame tiled over 4 or 8 GPUs, small images): one wave per 8x8 pixels running all samples
+// fills the machine for about one round, and the launch lasts as long as its slowest wave.  The samples of a pixel are
+// independent up to the ordered sum and the last-writer reservoir, so the launch is cut into sample groups (workgroup =
+// tile x group) and a resolve pass puts the pixel together in sample order: same values, several rounds of shorter waves.
+template <class TR>
+__global__ void __launch_bounds__(256, HRT_PT_WAVES)
+hrt_path_trace_split_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
+                            long long nPix, TileMap tm, hrt_float3* li, float* stage, int nGroups, int perGroup)
+{
+    Cnt<false> C;
+    const int g = blockIdx.x / tm.nTiles;
+    SplitK sk;
+    sk.li = li; sk.stage = stage; sk.group = g; sk.nGroups = nGroups;
+    sk.sBegin = g * perGroup; sk.sEnd = min(sk.sBegin + perGroup, max(1, k.spp));
+    int x, y;
+    if (tile_pixel(tm, k, x, y, blockIdx.x - g * tm.nTiles)) path_trace_pixel<TR, false, true>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C, &sk);
+}
+
+__global__ void __launch_bounds__(256)
+hrt_split_resolve_kernel(FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resCur, long long nPix, TileMap tm, const hrt_float3* li, const float* stage, int nGroups)
+{
+    int x, y;
+    if (tile_pixel(tm, k, x, y, blockIdx.x)) split_resolve_pixel(k, gb, fb, resCur, nPix, y * k.width + x, li, stage, nGroups);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -273,6 +297,7 @@ struct DeviceState {
     float* wf_mem = nullptr; size_t wf_bytes = 0;
     int* wf_cnt = nullptr; size_t wf_cnt_ints = 0;
     int* wf_ovf = nullptr;                     // wide walker stack overflow area (allocated on first use)
+    float* split_mem = nullptr; size_t split_floats = 0;    // fused kernel in sample groups: per-sample radiance + staged reservoirs
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
     int64_t nPix = 0;
     DGBuffer gb{};
@@ -391,6 +416,8 @@ void free_workspace(DeviceState& d)
     if (d.wf_cnt) (void)hipFree(d.wf_cnt);
     if (d.wf_ovf) (void)hipFree(d.wf_ovf);
     d.wf_ovf = nullptr;
+    if (d.split_mem) (void)hipFree(d.split_mem);
+    d.split_mem = nullptr; d.split_floats = 0;
     d.wf_mem = nullptr; d.wf_cnt = nullptr; d.wf_bytes = 0; d.wf_cnt_ints = 0;
 }
 
@@ -817,6 +844,35 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     if (mega || k.maxDepth > 64)
     {
         const dim3 grid(tm.nTiles), block(64 * tm.wpb);
+        // sample groups when the tile gives the machine less than ~3 rounds of waves
+        static const int splitEnv = getenv("HRT_SPLIT") ? atoi(getenv("HRT_SPLIT")) : -1;          // A/B knob: 0 never, n > 0 force n groups
+        const int sppN = k.spp > 1 ? k.spp : 1;
+        const long long waves = (long long)tm.nTiles * tm.wpb, slots = (long long)d.n_cu * 4 * HRT_PT_WAVES;
+        int nGroups = 1;
+        if (!count && k.maxDepth <= 64 && sppN > 1 && waves > 0)
+        {
+            if (splitEnv > 0) nGroups = std::min(splitEnv, sppN);
+            else if (splitEnv < 0 && waves < 3 * slots) nGroups = (int)std::min<long long>(std::min(sppN, 8), (4 * slots + waves - 1) / waves);
+        }
+        if (nGroups > 1)
+        {
+            const int perGroup = (sppN + nGroups - 1) / nGroups;
+            nGroups = (sppN + perGroup - 1) / perGroup;
+            const size_t need = ((size_t)sppN * 3 + (size_t)nGroups * 12) * (size_t)nPix;
+            if (need > d.split_floats)
+            {
+                if (d.split_mem) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.split_mem); d.split_mem = nullptr; d.split_floats = 0; }
+                void* v = nullptr;
+                HIPCHK(c, hipMalloc(&v, need * sizeof(float)));
+                d.split_mem = (float*)v; d.split_floats = need;
+            }
+            hrt_float3* li = (hrt_float3*)d.split_mem;
+            float* stage = d.split_mem + (size_t)sppN * 3 * (size_t)nPix;
+            hipLaunchKernelGGL((hrt_path_trace_split_kernel<TR>), dim3(tm.nTiles * nGroups), block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, li, stage, nGroups, perGroup);
+            hipLaunchKernelGGL(hrt_split_resolve_kernel, grid, block, 0, d.stream, k, d.gb, d.fb, resCur, nPix, tm, (const hrt_float3*)li, (const float*)stage, nGroups);
+            HIPCHK(c, hipGetLastError());
+            return HRT_OK;
+        }
         if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
         else       hipLaunchKernelGGL((hrt_path_trace_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
         HIPCHK(c, hipGetLastError());
