@@ -212,6 +212,13 @@ def test_strip_interleaved_tiles_equal_full_frame(renderer):
             rays += st.k[1].rays_closest + st.k[1].rays_shadow
         H.assert_outputs_equal(full, arrs)
         assert rays == fst.k[1].rays_closest + fst.k[1].rays_shadow
+        # the production kernels on the same tiles: small tiles run the fused kernel in sample groups + ordered resolve
+        for flags in (0, T.FLAG_STREAMED):
+            arrs2, o2 = T.alloc_outputs(w, h)
+            renderer.reset_history()
+            for i in range(n):
+                renderer.render_params(p, o2, flags=flags, strips=(n, i))
+            H.assert_outputs_equal(full, arrs2)
 
 
 def test_async_frames_and_synchronize(renderer):
