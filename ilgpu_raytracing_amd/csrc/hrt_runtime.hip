@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256)
 hrt_wf_init_kernel(FrameK k, WfGeom g, DGBuffer gb, WfBuffers W)
 {
     int range = wf_range(W.nRanges);
-    if (range >= 0) wf_init_wave<COUNT>(k, g, gb, W, range);
+    wf_init_wave<COUNT>(k, g, gb, W, range);      // every wave takes part in the workgroup's packing
 }
 
 template <bool COUNT>
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256)
 hrt_wf_finish_kernel(TracerPackedT<FEAT> tr, FrameK k, WfBuffers W, int vsel, int depth)
 {
     int range = wf_range(W.nRanges);
-    if (range >= 0) wf_finish_wave<FEAT, COUNT>(tr, k, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range);
+    wf_finish_wave<FEAT, COUNT>(tr, k, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range);      // every wave: the four waves of a workgroup pack their survivors together
 }
 
 __global__ void __launch_bounds__(256)

@@ -109,10 +109,33 @@ HRT_D int wave_prefix(bool keep, int& total)
 template <bool COUNT>
 HRT_D void wf_init_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const WfBuffers& W, int range)
 {
-    const int lane = threadIdx.x & 63;
+    // live paths of the four ranges of a workgroup are packed together, as in wf_finish_wave
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long base = (long long)range * kRange;
     const long long nPaths = (long long)g.batchCount * g.nOrd;
-    int outCount = 0;
+    int mine = 0;
+    if (range >= 0)
+        for (int it = 0; it < kRange / 64; it++)
+        {
+            const long long pid = base + it * 64 + lane;
+            bool live = false;
+            if (pid < nPaths)
+            {
+                const int s = (int)(pid / g.nOrd);
+                int x, y;
+                if (ord_pixel(g, k, (int)(pid - (long long)s * g.nOrd), x, y)) live = gb.hitMask[y * k.width + x] != 0;
+            }
+            mine += __popcll(__ballot(live));
+        }
+    if (lane == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    int before = 0, groupTotal = 0;
+    for (int j = 0; j < 4; j++) { const int cj = s_cnt[j]; if (j < wv) before += cj; groupTotal += cj; }
+    if (range < 0) return;
+    const int groupRange = range & ~3;
+    const long long groupBase = (long long)groupRange * kRange;
+    int outCount = before;
     for (int it = 0; it < kRange / 64; it++)
     {
         long long pid = base + it * 64 + lane;
@@ -134,7 +157,7 @@ HRT_D void wf_init_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, co
         int off = wave_prefix(live, total);
         if (live)
         {
-            long long slot = base + outCount + off;
+            long long slot = groupBase + outCount + off;
             const F3 gpos = ld3(&gb.worldPos[index]);
             const int packedMat = gb.matId[index];
             W.A.st3(V_POS, slot, gpos);
@@ -151,7 +174,7 @@ HRT_D void wf_init_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, co
         }
         outCount += total;
     }
-    if (lane == 0) W.cntA[range] = outCount;
+    if (lane == 0) W.cntA[range] = max(0, min(kRange, groupTotal - (range - groupRange) * kRange));
 }
 
 // ------------------------------------------------------------------ shade: vertex -> ray requests (RTRay.cs:235-312)
@@ -474,14 +497,40 @@ HRT_D void wf_walkw_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers&
 }
 
 // next vertex or end of path from the raw winners (TraceNext :659-671, :241-243), with segmented compaction
+// The four waves of a workgroup own four consecutive ranges.  Their survivors are packed TOGETHER into the front of that
+// 1024-slot group (a path may change range: everything it owns travels by path id), so the next bounce sees a few full
+// ranges and empty ones instead of four ranges with a few dozen live paths each -- fuller waves in wf_shade, wf_finish and
+// the static walk launches.  Pass 1 counts each wave's survivors (flags and hit distance only), pass 2 is the real work
+// with the block-wide offset.  range < 0: a wave past the end that still takes part in the barrier.
 template <int FEAT, bool COUNT>
 HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const WfBuffers& W, const Planes& V, const Planes& Vn, int depth, int range)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long base = (long long)range * kRange;
-    const int n = W.cntA[depth * W.nRanges + range];
+    const int n = range >= 0 ? W.cntA[depth * W.nRanges + range] : 0;
     const bool lastDepth = depth + 1 >= k.maxDepth;
-    int outCount = 0;
+    int mine = 0;
+    if (!lastDepth)
+        for (int it = 0; it * 64 < n; it++)
+        {
+            const int i = it * 64 + lane;
+            bool sv = false;
+            if (i < n)
+            {
+                const float4 qb = W.R.ld4(RQ_B, base + i);
+                if (!(__float_as_int(qb.z) & RF_DEAD)) sv = W.R.ld4(RQ_H, base + i).x < 1e29f;
+            }
+            mine += __popcll(__ballot(sv));
+        }
+    if (lane == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    int before = 0, groupTotal = 0;
+    for (int j = 0; j < 4; j++) { const int cj = s_cnt[j]; if (j < wv) before += cj; groupTotal += cj; }
+    if (range < 0) return;
+    const int groupRange = range & ~3;
+    const long long groupBase = (long long)groupRange * kRange;
+    int outCount = before;
     for (int it = 0; it * 64 < n; it++)
     {
         const int i = it * 64 + lane;
@@ -517,7 +566,7 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
         int off = wave_prefix(survive, total);
         if (survive)
         {
-            long long o = base + outCount + off;
+            long long o = groupBase + outCount + off;
             Vn.st3(V_POS, o, r.o + r.d * h.t);
             Vn.st3(V_NRM, o, normalize(h.n));
             Vn.st3(V_ALB, o, h.albedo);
@@ -532,7 +581,8 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
         }
         outCount += total;
     }
-    if (lane == 0) W.cntA[(depth + 1) * W.nRanges + range] = outCount;
+    // range j of the group now holds survivors [256 j, 256 j + 256) of the group
+    if (lane == 0) W.cntA[(depth + 1) * W.nRanges + range] = max(0, min(kRange, groupTotal - (range - groupRange) * kRange));
 }
 
 // ------------------------------------------------------------------ resolve: ordered sample sum, reservoir hand-off, framebuffer store (:320-324)
