@@ -3,10 +3,11 @@
 // Measured on the one-ray-per-lane walk (profiles/r01_pmc_config3_*): the traversal kernels are
 // VALU-bound but only ~16 % of the lanes of an executed instruction are live -- a wave runs
 // until its LONGEST ray is done (sky rays leave after a few nodes, grazing rays visit
-// hundreds).  Here a wave owns a queue of n rays and keeps its 64 lanes full: each lane carries
-// a resumable walk state (which tree, which node, which leaf entry), and whenever >= kRefillMin
-// lanes have finished, one __ballot + popcount prefix hands each of them the next unfetched ray
-// of the queue.  Every iteration all walking lanes take a node step together (TLAS and BLAS
+// hundreds).  Here a wave owns a queue of rays -- one path range, or a chain of ranges it pulls
+// from the launch-wide hand-out (RangeGrab, hrt_wavefront.hpp) -- and keeps its 64 lanes full:
+// each lane carries a resumable walk state (which tree, which node, which leaf entry), and
+// whenever >= kRefillMin lanes have finished, one __ballot + popcount prefix hands each of them
+// the next unfetched ray of the queue.  Every iteration all walking lanes take a node step together (TLAS and BLAS
 // nodes share the code: same 32-byte NodeQ, same box test), then lanes standing on a leaf entry
 // take one primitive step.  A ray's sequence of node visits, box tests and primitive tests is
 // exactly the reference's (SceneDeviceViews.cs:30-327), so hits, tie-breaks and work counters
