@@ -288,7 +288,7 @@ struct DeviceState {
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
-    void* packed[6] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
+    void* packed[7] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
     DPacked dpacked{};
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
@@ -424,7 +424,7 @@ void free_workspace(DeviceState& d)
 void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
-    for (int i = 0; i < 6; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
+    for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -437,9 +437,11 @@ struct PackedHost {
     std::vector<NodeQ> tlas, blas, flat;     // flat: the TLAS leaves in walk order (TracerFlat)
     std::vector<FInst> finst;
     std::vector<FTri> ftri;
+    std::vector<NodeQ> tlasX; // FEAT 0: TLAS with instance records inlined after their leaf (walker)
     std::vector<WNode> wide;  // 4-wide collapse of the TLAS and of every BLAS range (wide walker)
     int wide_tlas_root = kWNone;
     int wide_depth = 0;       // wide levels of the TLAS + of the deepest BLAS (stack bound of the wide walker); 0: not built
+    int n_tlasX = 0;          // records in tlasX (0: not built)
     int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
@@ -741,6 +743,38 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     }
     if (out.wide.empty()) { out.wide.assign(1, WNode{}); out.wide_depth = 0; }
     (void)wideDepthMax;
+
+    // ---- sphere-instance scenes: instance records inlined into the TLAS node stream (hrt_walker.hpp).  A leaf is followed by
+    // one record per instance holding the box of its one-node BLAS; the walker treats them as nodes (count field 15), so the
+    // instance box tests ride the node steps and their lookahead instead of costing a leaf step each.
+    out.tlasX.assign(1, NodeQ{});
+    if (out.ok && out.feat == 0 && reachableT > 0 && nT + nTI < kEnd && !getenv("HRT_NO_INLINE_INSTANCES"))
+    {
+        std::vector<int32_t> nidx((size_t)nT);
+        int32_t at = 0;
+        auto cnt_of = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.tlas[(size_t)i].hi.w) >> 28); };
+        for (int64_t i = 0; i < nT; i++) { nidx[(size_t)i] = at; at += 1 + cnt_of(i); }
+        auto remap = [&](int v) { return v == kEnd ? kEnd : (int)nidx[(size_t)v]; };
+        out.tlasX.assign((size_t)at, NodeQ{});
+        for (int64_t i = 0; i < nT; i++)
+        {
+            const NodeQ& q = out.tlas[(size_t)i];
+            const int c = cnt_of(i), link = __builtin_bit_cast(int, q.lo.w), sk = remap(__builtin_bit_cast(int, q.hi.w) & kEnd);
+            NodeQ& o = out.tlasX[(size_t)nidx[(size_t)i]];
+            o = q;
+            o.hi.w = bits_f(sk | (int)((unsigned)c << 28));
+            if (c == 0) { o.lo.w = bits_f(remap(link & kEnd)); continue; }
+            for (int j = 0; j < c; j++)
+            {
+                const FInst& f = out.finst[(size_t)(link + j)];
+                NodeQ& r = out.tlasX[(size_t)(nidx[(size_t)i] + 1 + j)];
+                r.lo = mkf4(f.a.x, f.a.y, f.a.z, bits_f(link + j));
+                const int next = (j + 1 < c) ? nidx[(size_t)i] + 2 + j : sk;
+                r.hi = mkf4(f.b.x, f.b.y, f.b.z, bits_f(next | (int)(15u << 28)));
+            }
+        }
+        out.n_tlasX = at;
+    }
 
     // TracerFlat: the reachable TLAS leaves in walk order, for scenes made of fast-sphere instances only
     out.flat.assign(1, NodeQ{});
@@ -1151,10 +1185,10 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
         // device-private repack (TracerPacked)
-        const void* psrc[6] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), ph.wide.data()};
-        const size_t pbytes[6] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
-                                  ph.flat.size() * sizeof(NodeQ), ph.wide.size() * sizeof(WNode)};
-        for (int i = 0; i < 6; i++)
+        const void* psrc[7] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), ph.wide.data(), ph.tlasX.data()};
+        const size_t pbytes[7] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
+                                  ph.flat.size() * sizeof(NodeQ), ph.wide.size() * sizeof(WNode), ph.tlasX.size() * sizeof(NodeQ)};
+        for (int i = 0; i < 7; i++)
         {
             HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
@@ -1163,6 +1197,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
         d.dpacked.nTlas = (int)ph.tlas.size();
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
+        d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;

@@ -50,6 +50,8 @@ struct DPacked {
     const NodeQ* blas;       // indexed like blasNodes
     const FTri* ftri;        // indexed like triPrimIdx
     int nTlas;               // records in tlas (>= 1)
+    const NodeQ* tlasX;      // sphere-instance scenes (FEAT 0): the TLAS with every leaf followed by one record per instance
+    int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
     const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
 };

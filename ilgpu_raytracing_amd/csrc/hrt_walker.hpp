@@ -56,6 +56,9 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
 {
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
+    // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
+    // into them, an instance-record hit leaves ONE sphere test pending for the leaf step
+    const bool inl = !kGeneral && tr.P.tlasX != nullptr;
     __shared__ float park_mem[kGeneral ? 9 : 1][256];
     RayPark park; park.sh = park_mem;
     const DPacked& P = tr.P;
@@ -127,11 +130,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             if (walking)
             {
                 const bool top = !kGeneral || mode == M_TLAS;
-                const NodeQ* nodes = top ? P.tlas : P.blas;
+                const NodeQ* nodes = top ? (inl ? P.tlasX : P.tlas) : P.blas;
                 // In walk order the node entered after a hit on an inner node is the next record, usually in the same
                 // 128-byte line: it is fetched together with the node itself, so a hit costs no second memory round trip
                 // (the walk is bound by the latency of dependent loads, not by their number).
-                const int last = (top ? P.nTlas : blasEnd) - 1;
+                const int last = (top ? (inl ? P.nTlasX : P.nTlas) : blasEnd) - 1;
                 // kLook consecutive records leave together (one or two 128-byte lines)
                 NodeQ nds[kLook];
 #pragma unroll
@@ -148,12 +151,19 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     sk &= kEnd;
                     const int here = cur;
                     bool stay = true;                    // still walking nodes of the same tree after this node
-                    if (!hit_box(w, nd.lo, nd.hi, 0.001f, lim)) cur = sk;
+                    const bool isInst = inl && cnt == 15;        // the one-node BLAS of an instance (its box test takes tMax, not the closest t)
+                    if (isInst) C.inc(C_LEAF_INST);
+                    if (!hit_box(w, nd.lo, nd.hi, 0.001f, isInst ? (ANY ? tMaxW : 1e30f) : lim)) cur = sk;
+                    else if (isInst) { stay = false; li = wbits(nd.lo); lskip = sk; mode = M_TLEAF; }
                     else if (cnt > 0)
                     {
-                        stay = false;
-                        if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
-                        else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
+                        if (inl) cur = here + 1;         // its instance records follow
+                        else
+                        {
+                            stay = false;
+                            if (top) { li = wbits(nd.lo); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
+                            else     { bj = wbits(nd.lo); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
+                        }
                     }
                     else cur = wbits(nd.lo) & kEnd;
                     // the record after `here` is the next node after a hit on an inner node AND after a missed leaf (a
@@ -172,7 +182,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                 w = park.get();
                 mode = M_TLEAF;
             }
-            if (mode == M_TLEAF && li == lend) { cur = lskip; mode = M_TLAS; }
+            if (!inl && mode == M_TLEAF && li == lend) { cur = lskip; mode = M_TLAS; }
             if (mode == M_TLAS && cur == kEnd) mode = M_DONE;
         }
 
@@ -182,7 +192,20 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
         { const int a = __popcll(__ballot(mode == M_TLEAF)); if (a) { WSTAT(3, 1); WSTAT(4, a); }
           const int b = __popcll(__ballot(kGeneral && mode == M_BLEAF)); if (b) { WSTAT(5, 1); WSTAT(6, b); } }
 #endif
-        if (mode == M_TLEAF)
+        if (inl && mode == M_TLEAF)
+        {   // the sphere of the instance record whose box was hit
+            const float4 fb = P.finst[li].b, fc = P.finst[li].c;
+            const float lim = ANY ? tMaxW : 1e30f;
+            C.inc(C_SPHERE_TESTS);
+            float t;
+            if (hit_sphere_t(w, xyz(fc), fc.w, t) && t > 0.001f && t < lim)
+            {
+                if (ANY) { occl = true; mode = M_DONE; }
+                else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); }
+            }
+            if (mode == M_TLEAF) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
+        }
+        else if (mode == M_TLEAF)
         {
             FInst f = P.finst[li];
             C.inc(C_LEAF_INST);
