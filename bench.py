@@ -105,8 +105,8 @@ def cpu_baseline(cfg_id, cfg, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (non-default => not the headline config)")
