@@ -61,10 +61,10 @@ enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG =
 // ray request written by wf_shade for the same slot
 // RQ_A = (o.xyz, d.x)  RQ_B = (d.yz, flags, rng)  RQ_H = raw winner of the closest-hit walk (t, tObj, leaf slot, primitive): 16-byte records
 enum { RQ_A = 0, RQ_B = 4, R_T = 8, RQ_H = 11, R_PLANES = 15 };
-enum { RF_DEAD = 1, RF_WROTE = 2 };          // R_FLG / V_MAT(bit 16+) flags
+enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROTE also in V_MAT bit 17); RF_SHADOW: bits 8..15 = the vertex' shadow request, relative to its range
 // shadow request (compacted per range)
 // SQ_A = (o.xyz, d.x)  SQ_B = (d.yz, slot in range, add.x): 16-byte records; add.yz in two planes
-enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_PLANES = 10 };
+enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_VIS = 10, S_PLANES = 11 };      // S_VIS: 1 once the walk found the request unoccluded
 // reservoir staging per path id
 enum { G_L = 0, G_WI = 3, G_PDF = 6, G_W = 7, G_WSUM = 8, G_M = 9, G_LID = 10, G_FLAG = 11, G_PLANES = 12 };
 
@@ -192,16 +192,18 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
         const bool valid = i < n;
         const long long slot = base + i;
         bool wantShadow = false;
-        F3 so = mk3(0.f, 0.f, 0.f), sd = so, sadd = so;
+        F3 so = mk3(0.f, 0.f, 0.f), sd = so, sadd = so, T = so;
+        Rng rng; rng.s = 0;
+        int flg = 0;
+        Ray ray; ray.o = so; ray.d = so;
         if (valid)
         {
             const F3 pos = V.ld3(V_POS, slot), nrm = V.ld3(V_NRM, slot), alb = V.ld3(V_ALB, slot), I = V.ld3(V_IDIR, slot);
-            F3 T = V.ld3(V_T, slot);
-            Rng rng; rng.s = (uint32_t)V.ldi(V_RNG, slot);
+            T = V.ld3(V_T, slot);
+            rng.s = (uint32_t)V.ldi(V_RNG, slot);
             const int mat = V.ldi(V_MAT, slot);
             const int shade = mat & 0xFFFF;
-            int flg = (mat >> 16) & RF_WROTE;
-            Ray ray;
+            flg = (mat >> 16) & RF_WROTE;
             if (shade == HRT_SHADING_MIRROR)
             {   // :235-244
                 F3 dirR = I - nrm * (2.f * dot(I, nrm));
@@ -287,9 +289,6 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
                     else T = T * (1.0f / maxC);
                 }
             }
-            W.R.st4(RQ_A, slot, mkq(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
-            W.R.st4(RQ_B, slot, mkq(ray.d.y, ray.d.z, __int_as_float(flg), __int_as_float((int)rng.s)));
-            W.R.st3(R_T, slot, T);
         }
         int total;
         int off = wave_prefix(wantShadow, total);
@@ -299,6 +298,14 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
             W.SQ.st4(SQ_A, q, mkq(so.x, so.y, so.z, sd.x));
             W.SQ.st4(SQ_B, q, mkq(sd.y, sd.z, __int_as_float((int)(slot - base)), sadd.x));
             W.SQ.stf(S_ADDY, q, sadd.y); W.SQ.stf(S_ADDZ, q, sadd.z);
+            W.SQ.sti(S_VIS, q, 0);
+            flg |= RF_SHADOW | ((sqCount + off) << 8);        // wf_finish adds the direct light if the walk leaves S_VIS set
+        }
+        if (valid)
+        {
+            W.R.st4(RQ_A, slot, mkq(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
+            W.R.st4(RQ_B, slot, mkq(ray.d.y, ray.d.z, __int_as_float(flg), __int_as_float((int)rng.s)));
+            W.R.st3(R_T, slot, T);
         }
         sqCount += total;
     }
@@ -427,12 +434,7 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W
             r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d); tMax = 1e29f; return true;
         },
         [&](int q, const WalkResult& res) {
-            if (!res.occluded)
-            {
-                const float4 qb = W.SQ.ld4(SQ_B, q);
-                const long long slot = (long long)(q & ~(kRange - 1)) + __float_as_int(qb.z);
-                V.st3(V_LI, slot, V.ld3(V_LI, slot) + mk3(qb.w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q)));
-            }
+            if (!res.occluded) W.SQ.sti(S_VIS, q, 1);         // wf_finish_wave adds the request's light to its vertex
         }, C);
 }
 
@@ -468,12 +470,7 @@ HRT_D void wf_walkw_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& 
             r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d); tMax = 1e29f; return true;
         },
         [&](int q, const WalkResult& res) {
-            if (!res.occluded)
-            {
-                const float4 qb = W.SQ.ld4(SQ_B, q);
-                const long long slot = (long long)(q & ~(kRange - 1)) + __float_as_int(qb.z);
-                V.st3(V_LI, slot, V.ld3(V_LI, slot) + mk3(qb.w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q)));
-            }
+            if (!res.occluded) W.SQ.sti(S_VIS, q, 1);         // wf_finish_wave adds the request's light to its vertex
         });
 }
 
@@ -537,11 +534,19 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
         const long long slot = base + i;
         bool survive = false;
         Hit h; Ray r;
+        F3 Li = mk3(0.f, 0.f, 0.f);
         if (i < n)
         {
             const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
-            const bool dead = (__float_as_int(qb.z) & RF_DEAD) != 0;
+            const int flg = __float_as_int(qb.z);
+            const bool dead = (flg & RF_DEAD) != 0;
             bool missed = false;
+            Li = V.ld3(V_LI, slot);
+            if (flg & RF_SHADOW)
+            {   // direct light of this vertex, if its shadow walk found the light unoccluded (:286/:291)
+                const long long q = base + ((flg >> 8) & 0xFF);
+                if (W.SQ.ldi(S_VIS, q)) Li = Li + mk3(W.SQ.ld4(SQ_B, q).w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q));
+            }
             if (!dead)
             {
                 r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = mk3(0.f, 0.f, 0.f);
@@ -557,7 +562,6 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
             if (!survive)
             {
                 const int pid = V.ldi(V_PID, slot);
-                F3 Li = V.ld3(V_LI, slot);
                 if (missed) Li = Li + W.R.ld3(R_T, slot) * sky(k, r.d);
                 W.sampleLi.st3(0, pid, Li);
             }
@@ -572,7 +576,7 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
             Vn.st3(V_ALB, o, h.albedo);
             Vn.st3(V_IDIR, o, r.d);
             Vn.st3(V_T, o, W.R.ld3(R_T, slot));
-            Vn.st3(V_LI, o, V.ld3(V_LI, slot));
+            Vn.st3(V_LI, o, Li);
             const float4 qb2 = W.R.ld4(RQ_B, slot);
             Vn.sti(V_RNG, o, __float_as_int(qb2.w));
             Vn.sti(V_PID, o, V.ldi(V_PID, slot));
