@@ -92,6 +92,14 @@ SCENE_ARRAYS = [
 ]
 
 
+REBUILD_AUTO, REBUILD_FORCE_REFIT, REBUILD_FORCE_REBUILD = 0, 1, 2      # hrt_rebuild_policy = RebuildPolicy (BvhManager.cs:13-18)
+
+
+class BvhUpdateStats(C.Structure):    # hrt_bvh_update_stats
+    _fields_ = [("action", C.c_int32), ("tlas_nodes", C.c_int32), ("tlas_slots", C.c_int32), ("general_instances", C.c_int32),
+                ("growth_refit", C.c_float), ("growth_final", C.c_float), ("sah_cost", C.c_float), ("device_ms", C.c_float)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [f for name, t in SCENE_ARRAYS for f in ((name, C.POINTER(t)), ("n_" + name, C.c_int64))]
 

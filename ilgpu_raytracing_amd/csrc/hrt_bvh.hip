@@ -1,0 +1,457 @@
+// hrt_bvh.hip -- kernels behind hrt_scene_update_instances (see hrt_bvh.hpp for what they replace in the reference).
+//
+// All of it is small integer / min-max work over arrays of a few bytes per instance: one thread per instance, leaf
+// slot or node, coalesced where the numbering allows, no LDS tiling.  The only ordering problems are the bottom-up
+// box pass (solved with one arrival counter per inner node, release/acquire at agent scope) and the sort of the
+// Morton keys (hipCUB radix sort, stable, so equal keys keep instance order and the tree is deterministic).
+#include "hrt_bvh.hpp"
+#include <hipcub/hipcub.hpp>
+#include <cfloat>
+
+namespace hrt {
+namespace {
+
+constexpr int kBlock = 256;
+inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
+
+HRT_D int f2i(float f) { return __float_as_int(f); }
+HRT_D float i2f(int i) { return __int_as_float(i); }
+HRT_D int node_cnt(const NodeQ* n, int i) { return (int)((unsigned)f2i(n[i].hi.w) >> 28); }
+HRT_D int node_skip(const NodeQ* n, int i) { return f2i(n[i].hi.w) & kEnd; }
+HRT_D int node_link(const NodeQ* n, int i) { return f2i(n[i].lo.w); }
+
+// Scene.cs:475-493 / host xpoint, xvector: same expression order
+HRT_D F3 xf_point(const hrt_affine3x4& m, F3 p)
+{
+    return mk3(m.m00 * p.x + m.m01 * p.y + m.m02 * p.z + m.m03, m.m10 * p.x + m.m11 * p.y + m.m12 * p.z + m.m13, m.m20 * p.x + m.m21 * p.y + m.m22 * p.z + m.m23);
+}
+HRT_D F3 xf_vector(const hrt_affine3x4& m, F3 v)
+{
+    return mk3(m.m00 * v.x + m.m01 * v.y + m.m02 * v.z, m.m10 * v.x + m.m11 * v.y + m.m12 * v.z, m.m20 * v.x + m.m21 * v.y + m.m22 * v.z);
+}
+HRT_D F3 min3(F3 a, F3 b) { return mk3(hrt_fmin(a.x, b.x), hrt_fmin(a.y, b.y), hrt_fmin(a.z, b.z)); }
+HRT_D F3 max3(F3 a, F3 b) { return mk3(hrt_fmax(a.x, b.x), hrt_fmax(a.y, b.y), hrt_fmax(a.z, b.z)); }
+HRT_D bool is_identity(const hrt_affine3x4& m)
+{
+    return m.m00 == 1.f && m.m01 == 0.f && m.m02 == 0.f && m.m03 == 0.f && m.m10 == 0.f && m.m11 == 1.f && m.m12 == 0.f && m.m13 == 0.f &&
+           m.m20 == 0.f && m.m21 == 0.f && m.m22 == 1.f && m.m23 == 0.f;
+}
+
+// ------------------------------------------------------------------ instance records
+// One thread per moved instance.  The object-space box is the box of the instance's BLAS root node: both builders of the
+// reference make it the union of all primitive boxes, which is what BuildSphereInstance / LoadObjInstance transform
+// (Scene.cs:395-399, ComputeMeshBounds :582-595).
+__global__ void __launch_bounds__(kBlock) k_set_transforms(TlasDevice T, const int32_t* ids, const hrt_affine3x4* xf, int n)
+{
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const int ii = ids[k];
+    hrt_instance* in = T.instances + ii;
+    const hrt_affine3x4 m = xf[k];
+    F3 bmin = mk3(0.f, 0.f, 0.f), bmax = bmin;
+    if (in->blasNodeCount > 0)
+    {
+        const hrt_bvh_node* root = T.blasNodes + in->blasRoot;
+        bmin = cv3(root->boundsMin); bmax = cv3(root->boundsMax);
+    }
+    // TransformAABB, Scene.cs:560-580
+    const F3 c[8] = {mk3(bmin.x, bmin.y, bmin.z), mk3(bmax.x, bmin.y, bmin.z), mk3(bmin.x, bmax.y, bmin.z), mk3(bmin.x, bmin.y, bmax.z),
+                     mk3(bmax.x, bmax.y, bmin.z), mk3(bmin.x, bmax.y, bmax.z), mk3(bmax.x, bmin.y, bmax.z), mk3(bmax.x, bmax.y, bmax.z)};
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int i = 0; i < 8; i++) { const F3 w = xf_point(m, c[i]); mn = min3(mn, w); mx = max3(mx, w); }
+    // InvertRigidOrUniform, Scene.cs:616-638
+    const F3 c0 = mk3(m.m00, m.m10, m.m20), c1 = mk3(m.m01, m.m11, m.m21), c2 = mk3(m.m02, m.m12, m.m22);
+    const float sx = hrt_sqrt(c0.x * c0.x + c0.y * c0.y + c0.z * c0.z), sy = hrt_sqrt(c1.x * c1.x + c1.y * c1.y + c1.z * c1.z),
+                sz = hrt_sqrt(c2.x * c2.x + c2.y * c2.y + c2.z * c2.z);
+    const float uni = (sx + sy + sz) / 3.f;
+    const float inv = uni > 0.f ? 1.f / uni : 1.f;
+    const F3 r0 = normalize(c0), r1 = normalize(c1), r2 = normalize(c2);
+    hrt_affine3x4 im;
+    im.m00 = r0.x * inv; im.m01 = r1.x * inv; im.m02 = r2.x * inv; im.m03 = 0.f;
+    im.m10 = r0.y * inv; im.m11 = r1.y * inv; im.m12 = r2.y * inv; im.m13 = 0.f;
+    im.m20 = r0.z * inv; im.m21 = r1.z * inv; im.m22 = r2.z * inv; im.m23 = 0.f;
+    const F3 it = xf_vector(im, mk3(m.m03, m.m13, m.m23)) * -1.f;
+    im.m03 = it.x; im.m13 = it.y; im.m23 = it.z;
+    in->objectToWorld = m;
+    in->worldToObject = im;
+    in->uniformScale = uni;
+    in->worldBoundsMin = to3(mn);
+    in->worldBoundsMax = to3(mx);
+}
+
+// ------------------------------------------------------------------ leaf slots (the FInst half of validate_and_pack)
+__global__ void __launch_bounds__(kBlock) k_leaf_slots(TlasDevice T)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nTI) return;
+    const int ii = T.tlasInst[i];
+    const hrt_instance in = T.instances[ii];
+    const bool ident = is_identity(in.objectToWorld) && is_identity(in.worldToObject) && in.uniformScale == 1.0f;
+    const bool sph = in.type == HRT_BLAS_SPHERESET;
+    FInst f;
+    bool fast = false;
+    if (sph && ident && in.blasNodeCount >= 1)
+    {
+        const hrt_bvh_node root = T.blasNodes[in.blasRoot];
+        const int end = in.blasRoot + in.blasNodeCount;
+        if (root.count == 1 && (root.skipIndex == -1 || root.skipIndex >= end))
+        {
+            const int sid = T.spherePrimIdx[root.first];
+            const hrt_sphere* sp = T.spheres + sid;
+            f.a = make_float4(root.boundsMin.X, root.boundsMin.Y, root.boundsMin.Z, i2f(FI_FAST_SPHERE | FI_IDENTITY | FI_SPHERESET));
+            f.b = make_float4(root.boundsMax.X, root.boundsMax.Y, root.boundsMax.Z, i2f(sid));
+            f.c = make_float4(sp->center.X, sp->center.Y, sp->center.Z, sp->radius);
+            fast = true;
+        }
+    }
+    if (!fast)
+    {
+        const float scale = in.uniformScale > 0.f ? in.uniformScale : 1.f;
+        f.a = make_float4(0.f, 0.f, 0.f, i2f((ident ? FI_IDENTITY : 0) | (sph ? FI_SPHERESET : 0)));
+        f.b = make_float4(0.f, 0.f, 0.f, i2f(ii));
+        f.c = make_float4(i2f(in.blasRoot), i2f(in.blasRoot + in.blasNodeCount), scale, 0.f);
+        atomicOr(T.flags, 1);
+    }
+    T.finst[i] = f;
+}
+
+// ------------------------------------------------------------------ boxes, bottom-up
+// One thread per node; leaves take the union of their instances' world bounds (BuildTLASNodeRecursive, Scene.cs:472-480)
+// and climb: the last child to arrive at an inner node unites the children (the chain left, left.skip, ... up to the
+// node's own skip link) and climbs on.  min / max are exact, so the order of arrival cannot change a bit.
+__global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nT) return;
+    NodeQ* nodes = T.tlas;
+    const int cnt = node_cnt(nodes, i);
+    if (cnt == 0) return;
+    const int first = node_link(nodes, i);
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int j = 0; j < cnt; j++)
+    {
+        const hrt_instance* in = T.instances + T.tlasInst[first + j];
+        mn = min3(mn, cv3(in->worldBoundsMin)); mx = max3(mx, cv3(in->worldBoundsMax));
+    }
+    nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
+    nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
+    int cur = i;
+    for (;;)
+    {
+        const int p = T.parent[cur];
+        if (p < 0) break;
+        const int old = __hip_atomic_fetch_add(T.arrive + p, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 < T.nchild[p]) break;
+        const int pskip = node_skip(nodes, p);
+        mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX); mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+        int c = node_link(nodes, p) & kEnd;
+        for (int guard = 0; c != kEnd && c != pskip && guard < 64; guard++)
+        {
+            const float4 lo = nodes[c].lo, hi = nodes[c].hi;
+            mn = min3(mn, mk3(lo.x, lo.y, lo.z)); mx = max3(mx, mk3(hi.x, hi.y, hi.z));
+            c = f2i(hi.w) & kEnd;
+        }
+        nodes[p].lo.x = mn.x; nodes[p].lo.y = mn.y; nodes[p].lo.z = mn.z;
+        nodes[p].hi.x = mx.x; nodes[p].hi.y = mx.y; nodes[p].hi.z = mx.z;
+        cur = p;
+    }
+}
+
+// ------------------------------------------------------------------ exclusive scans over the node list (one workgroup)
+// nidx[i] = i + leaf slots before node i (position in the TLAS with inlined instance records); lidx[i] = leaves before i
+__global__ void __launch_bounds__(1024) k_scan(TlasDevice T)
+{
+    __shared__ int sA[16], sB[16], carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
+    __syncthreads();
+    for (int base = 0; base < T.nT; base += 1024)
+    {
+        const int i = base + tid;
+        const int a = i < T.nT ? node_cnt(T.tlas, i) : 0, b = a > 0 ? 1 : 0;
+        int ia = a, ib = b;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const int ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
+            if (lane >= d) { ia += ua; ib += ub; }
+        }
+        if (lane == 63) { sA[wv] = ia; sB[wv] = ib; }
+        __syncthreads();
+        int offA = carry[0], offB = carry[1], totA = 0, totB = 0;
+        for (int w = 0; w < 16; w++) { if (w < wv) { offA += sA[w]; offB += sB[w]; } totA += sA[w]; totB += sB[w]; }
+        if (i < T.nT) { T.nidx[i] = i + offA + ia - a; T.lidx[i] = offB + ib - b; }
+        __syncthreads();
+        if (tid == 0) { carry[0] += totA; carry[1] += totB; }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ everything that is a function of the packed TLAS
+__global__ void __launch_bounds__(kBlock) k_derive(TlasDevice T)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nT) return;
+    const NodeQ q = T.tlas[i];
+    const int cnt = (int)((unsigned)f2i(q.hi.w) >> 28), skip = f2i(q.hi.w) & kEnd, link = f2i(q.lo.w);
+    // reference layout, in walk-order numbering (Scene.cs:705-714; leaf / inner conventions of BuildTLASNodeRecursive)
+    hrt_bvh_node* r = T.tlasNodes + i;
+    r->boundsMin.X = q.lo.x; r->boundsMin.Y = q.lo.y; r->boundsMin.Z = q.lo.z;
+    r->boundsMax.X = q.hi.x; r->boundsMax.Y = q.hi.y; r->boundsMax.Z = q.hi.z;
+    r->skipIndex = skip == kEnd ? -1 : skip;
+    if (cnt > 0) { r->left = -1; r->right = -1; r->first = link; r->count = cnt; }
+    else
+    {
+        const int l = link & kEnd;
+        int rr = -1;
+        if (l != kEnd) { const int s = node_skip(T.tlas, l); if (s != kEnd && s != skip) rr = s; }
+        r->left = l == kEnd ? -1 : l; r->right = rr; r->first = -1; r->count = 0;
+    }
+    // surface area of the box (unlinked nodes of an uploaded tree do not count) and the node's term of the SAH estimate
+    const float dx = q.hi.x - q.lo.x, dy = q.hi.y - q.lo.y, dz = q.hi.z - q.lo.z;
+    const bool linked = i == 0 || T.parent[i] >= 0;
+    T.sa[i] = linked ? 2.f * (dx * dy + dy * dz + dz * dx) : 0.f;
+    T.arrive[i] = cnt > 0 ? cnt : 1;          // the refit is over: the counters now carry the SAH weights for k_cost
+    // the TLAS with instance records inlined after their leaf (hrt_walker.hpp), as validate_and_pack lays it out
+    const int at = T.nidx[i];
+    const int skX = skip == kEnd ? kEnd : T.nidx[skip];
+    NodeQ o = q;
+    o.hi.w = i2f(skX | (int)((unsigned)cnt << 28));
+    if (cnt == 0) { const int l = link & kEnd; o.lo.w = i2f(l == kEnd ? kEnd : T.nidx[l]); }
+    T.tlasX[at] = o;
+    for (int j = 0; j < cnt; j++)
+    {
+        const FInst f = T.finst[link + j];
+        NodeQ rec;
+        rec.lo = make_float4(f.a.x, f.a.y, f.a.z, i2f(link + j));
+        const int next = (j + 1 < cnt) ? at + 2 + j : skX;
+        rec.hi = make_float4(f.b.x, f.b.y, f.b.z, i2f(next | (int)(15u << 28)));
+        T.tlasX[at + 1 + j] = rec;
+    }
+    if (cnt > 0 && T.lidx[i] < T.flatMax) T.flat[T.lidx[i]] = q;
+}
+
+// cost[0]: geometric mean over the nodes of area now / area when the tree was last built (1 = as built; a mean that one
+// far-flung instance or one huge instance cannot dominate); cost[1]: the classic estimate sum(area x (leaf ? count : 1)) / area(root).
+// Fixed summation order: reproducible, so HRT_REBUILD_AUTO takes the same decision for the same moves.
+__global__ void __launch_bounds__(1024) k_cost(TlasDevice T)
+{
+    __shared__ float s[3][1024];
+    float lg = 0.f, m = 0.f, sah = 0.f;
+    for (int i = threadIdx.x; i < T.nT; i += 1024)
+    {
+        const float a = T.sa[i], b = T.saBase[i];
+        sah += a * (float)T.arrive[i];
+        if (a > 0.f && b > 0.f) { lg += __logf(a / b); m += 1.f; }
+    }
+    s[0][threadIdx.x] = lg; s[1][threadIdx.x] = m; s[2][threadIdx.x] = sah;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d) for (int k = 0; k < 3; k++) s[k][threadIdx.x] += s[k][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        T.cost[0] = s[1][0] > 0.f ? __expf(s[0][0] / s[1][0]) : 1.f;
+        const float root = T.sa[0];
+        T.cost[1] = root > 0.f ? s[2][0] / root : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ LBVH topology
+HRT_D F3 inst_centroid(const hrt_instance* in)
+{   // the builder's sort key (Scene.cs:487-489): 0.5 * (min + max)
+    return mk3(0.5f * (in->worldBoundsMin.X + in->worldBoundsMax.X), 0.5f * (in->worldBoundsMin.Y + in->worldBoundsMax.Y),
+               0.5f * (in->worldBoundsMin.Z + in->worldBoundsMax.Z));
+}
+
+__global__ void __launch_bounds__(1024) k_centroid_bounds(TlasDevice T)
+{
+    __shared__ float s[6][16];
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int i = threadIdx.x; i < T.nI; i += 1024) { const F3 c = inst_centroid(T.instances + i); mn = min3(mn, c); mx = max3(mx, c); }
+    float v[6] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
+    for (int d = 32; d > 0; d >>= 1)
+        for (int k = 0; k < 6; k++) { const float o = __shfl_xor(v[k], d); v[k] = k < 3 ? hrt_fmin(v[k], o) : hrt_fmax(v[k], o); }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 6; k++) s[k][wv] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 6)
+    {
+        const int k = threadIdx.x;
+        float r = s[k][0];
+        for (int w = 1; w < 16; w++) r = k < 3 ? hrt_fmin(r, s[k][w]) : hrt_fmax(r, s[k][w]);
+        T.cbounds[k] = r;
+    }
+}
+
+HRT_D unsigned spread3(unsigned v)
+{   // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+HRT_D unsigned quant10(float c, float lo, float hi)
+{
+    const float ext = hi - lo;
+    const float n = ext > 0.f ? (c - lo) / ext : 0.f;
+    if (!(n > 0.f)) return 0u;
+    const float s = n * 1024.f;
+    return s >= 1023.f ? 1023u : (unsigned)(int)s;
+}
+
+__global__ void __launch_bounds__(kBlock) k_morton(TlasDevice T)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nI) return;
+    const F3 c = inst_centroid(T.instances + i);
+    const unsigned x = quant10(c.x, T.cbounds[0], T.cbounds[3]), y = quant10(c.y, T.cbounds[1], T.cbounds[4]), z = quant10(c.z, T.cbounds[2], T.cbounds[5]);
+    T.keys[i] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
+    T.vals[i] = i;
+}
+
+// leaf k = sorted slots [2k, 2k+2); its key is the key of its first slot; equal keys are told apart by k
+HRT_D int lbvh_delta(const unsigned* keys, int L, int a, int b)
+{
+    if (b < 0 || b >= L) return -1;
+    const unsigned ka = keys[2 * a], kb = keys[2 * b];
+    return ka != kb ? __clz((int)(ka ^ kb)) : 32 + __clz(a ^ b);
+}
+
+// one thread per inner node j of the L - 1 (Karras 2012): range of leaves, split, children
+__global__ void __launch_bounds__(kBlock) k_lbvh_inner(TlasDevice T, int L)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= L - 1) return;
+    const unsigned* keys = T.keysSorted;
+    const int d = lbvh_delta(keys, L, j, j + 1) - lbvh_delta(keys, L, j, j - 1) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, L, j, j - d);
+    int lmax = 2;
+    while (lbvh_delta(keys, L, j, j + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, L, j, j + (l + t) * d) > dmin) l += t;
+    const int e = j + l * d;
+    const int dnode = lbvh_delta(keys, L, j, e);
+    int s = 0, t = l;
+    do { t = (t + 1) >> 1; if (lbvh_delta(keys, L, j, j + (s + t) * d) > dnode) s += t; } while (t > 1);
+    const int g = j + s * d + min(d, 0);
+    const int a = min(j, e), b = max(j, e);
+    T.rngA[j] = a; T.rngB[j] = b; T.split[j] = g;
+    if (a == g) T.parLeaf[g] = j; else T.parInt[g] = j;
+    if (b == g + 1) T.parLeaf[g + 1] = j; else T.parInt[g + 1] = j;
+    if (j == 0) T.parInt[0] = -1;
+}
+
+// walk-order index of every node: the path from the root adds 1 per left edge and 1 + size(left subtree) per right edge;
+// a subtree over n leaves has 2n - 1 nodes.  node < L - 1: inner node; else leaf node - (L - 1).
+__global__ void __launch_bounds__(kBlock) k_lbvh_index(TlasDevice T, int L)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= 2 * L - 1) return;
+    const bool leaf = v >= L - 1;
+    int start = leaf ? v - (L - 1) : T.rngA[v];
+    int p = leaf ? T.parLeaf[v - (L - 1)] : T.parInt[v];
+    int idx = 0;
+    while (p >= 0)
+    {
+        const int g = T.split[p], a = T.rngA[p];
+        idx += start == g + 1 ? 2 * (g - a + 1) : 1;
+        start = a;
+        p = T.parInt[p];
+    }
+    if (leaf) T.idxLeaf[v - (L - 1)] = idx; else T.idxInt[v] = idx;
+}
+
+__global__ void __launch_bounds__(kBlock) k_lbvh_emit(TlasDevice T, int L)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    const int total = 2 * L - 1;
+    if (v >= total) return;
+    const bool leaf = v >= L - 1;
+    const int k = v - (L - 1);
+    const int idx = leaf ? T.idxLeaf[k] : T.idxInt[v];
+    const int leaves = leaf ? 1 : T.rngB[v] - T.rngA[v] + 1;
+    int skip = idx + 2 * leaves - 1;
+    if (skip >= total) skip = kEnd;
+    const int p = leaf ? T.parLeaf[k] : T.parInt[v];
+    T.parent[idx] = p < 0 ? -1 : T.idxInt[p];
+    NodeQ* q = T.tlas + idx;
+    if (leaf)
+    {
+        const int cnt = min(2, T.nI - 2 * k);
+        q->lo.w = i2f(2 * k);
+        q->hi.w = i2f(skip | (int)((unsigned)cnt << 28));
+        T.nchild[idx] = 0;
+    }
+    else
+    {
+        q->lo.w = i2f(idx + 1);
+        q->hi.w = i2f(skip);
+        T.nchild[idx] = 2;
+    }
+}
+
+__global__ void k_single_leaf(TlasDevice T)
+{   // <= 2 instances: the root is the only node
+    T.tlas[0].lo.w = i2f(0);
+    T.tlas[0].hi.w = i2f(kEnd | (int)((unsigned)T.nI << 28));
+    T.parent[0] = -1; T.nchild[0] = 0;
+    for (int i = 0; i < T.nI; i++) T.tlasInst[i] = i;
+}
+
+} // namespace
+
+size_t tlas_sort_temp_bytes(int n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, n, 0, 30, (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t tlas_set_transforms(const TlasDevice& T, const int32_t* idsDev, const hrt_affine3x4* xfDev, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    k_set_transforms<<<blocks_for(n), kBlock, 0, s>>>(T, idsDev, xfDev, n);
+    return hipGetLastError();
+}
+
+hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s)
+{
+    const int n = T.nI;
+    if (n <= 0) return hipErrorInvalidValue;
+    const int L = (n + 1) / 2;
+    T.nTI = n;
+    T.nT = 2 * L - 1;
+    if (T.nT > T.capT || T.nTI > T.capTI) return hipErrorInvalidValue;
+    if (L == 1)
+    {
+        k_single_leaf<<<1, 1, 0, s>>>(T);
+        return hipGetLastError();
+    }
+    k_centroid_bounds<<<1, 1024, 0, s>>>(T);
+    k_morton<<<blocks_for(n), kBlock, 0, s>>>(T);
+    size_t bytes = T.sortTmpBytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)T.tlasInst, n, 0, 30, s);
+    if (e != hipSuccess) return e;
+    k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L);
+    k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
+    k_lbvh_emit<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
+    return hipGetLastError();
+}
+
+hipError_t tlas_finish(const TlasDevice& T, hipStream_t s)
+{
+    hipError_t e;
+    if ((e = hipMemsetAsync(T.flags, 0, 4 * sizeof(int), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(T.arrive, 0, (size_t)T.nT * sizeof(int), s)) != hipSuccess) return e;
+    if (T.nTI > 0) k_leaf_slots<<<blocks_for(T.nTI), kBlock, 0, s>>>(T);
+    k_refit<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
+    k_scan<<<1, 1024, 0, s>>>(T);
+    k_derive<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
+    k_cost<<<1, 1024, 0, s>>>(T);
+    return hipGetLastError();
+}
+
+} // namespace hrt

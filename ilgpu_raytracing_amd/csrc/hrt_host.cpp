@@ -395,6 +395,23 @@ struct HostScene {
         return (int)instances.size() - 1;
     }
 
+    // a moved instance: the records BuildSphereInstance / LoadObjInstance derive from objectToWorld (Scene.cs:395-402,236-252);
+    // object-space bounds = box of the BLAS root (the union of all primitive boxes for both builders)
+    bool set_instance_transform(int id, const hrt_affine3x4& o2w)
+    {
+        if (id < 0 || id >= (int)instances.size()) return false;
+        hrt_instance& inst = instances[(size_t)id];
+        V3 bmin = v3(0.f, 0.f, 0.f), bmax = bmin;
+        if (inst.blasNodeCount > 0) { bmin = v3(blasNodes[(size_t)inst.blasRoot].boundsMin); bmax = v3(blasNodes[(size_t)inst.blasRoot].boundsMax); }
+        V3 wmin, wmax;
+        transform_aabb(o2w, bmin, bmax, wmin, wmax);
+        float uni;
+        hrt_affine3x4 w2o = invert_rigid_or_uniform(o2w, uni);
+        inst.objectToWorld = o2w; inst.worldToObject = w2o; inst.uniformScale = uni;
+        inst.worldBoundsMin = f3(wmin); inst.worldBoundsMax = f3(wmax);
+        return true;
+    }
+
     void rebuild_tlas()                         // Scene.cs:358-368,469-510
     {
         int n = (int)instances.size();
@@ -517,6 +534,11 @@ int hrth_scene_load_mesh_instance(void* s_, const hrt_float3* pos, int nPos, con
     return s->load_mesh_instance(pos, nPos, tris, nTris, tex, nTex, tuv, triMat, nTriMat, mats, nMats, texW, texH, texBGRA, nTextures, *m);
 }
 void hrth_scene_rebuild_tlas(void* s) { static_cast<HostScene*>(s)->rebuild_tlas(); }
+int hrth_scene_set_instance_transform(void* s, int id, const hrt_affine3x4* m)
+{
+    if (!s || !m) return -1;
+    return static_cast<HostScene*>(s)->set_instance_transform(id, *m) ? 0 : -1;
+}
 void hrth_scene_get_desc(void* s, hrt_scene_desc* d) { static_cast<HostScene*>(s)->get_desc(*d); }
 
 void hrth_camera_create(int width, int height, float fovDegrees, hrt_camera* out)      // Camera.cs:19-47

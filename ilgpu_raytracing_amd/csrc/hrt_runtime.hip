@@ -16,6 +16,7 @@
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
 #include "hrt_wavefront.hpp"
+#include "hrt_bvh.hpp"
 #include "hrt_post.hpp"
 #include "../../include/hip_raytrace.h"
 
@@ -290,6 +291,10 @@ struct DeviceState {
     DScene dscene{};
     void* packed[7] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
     DPacked dpacked{};
+    TlasDevice tl{};                           // device-side TLAS maintenance (hrt_bvh.hpp); aux arrays below
+    void* tlaux[9] = {};                       // parent, nchild, arrive, nidx, lidx, sa, flags, cost, saBase
+    void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
+    bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
@@ -320,6 +325,12 @@ struct hrt_ctx {
     int wide_depth = 0;                        // > 0: the 4-wide collapse exists; stack bound of the wide walker = 3 * wide_depth + 2
     int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
     bool small_scene = false;                  // <= kSmallSceneNodes BVH nodes: the walk is ALU-bound and L1-resident -> megakernel
+    // state of hrt_scene_update_instances
+    bool refit_ok = false;                     // every reachable TLAS node has one parent and <= 64 children
+    bool feat_alpha = false;                   // the triangle half of packed_feat (does not change with the TLAS)
+    int64_t n_inst = 0, n_tlas = 0, n_slots = 0, n_blas = 0;
+    int tlas_leaves = 0;                       // reachable leaves of the TLAS in use
+    bool tlas_on_device = false;               // the TLAS in use was refitted / rebuilt on the device (walk-order numbering)
     int width = 0, height = 0;
 };
 
@@ -425,6 +436,9 @@ void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
+    for (int i = 0; i < 9; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
+    if (d.tlscratch) (void)hipFree(d.tlscratch);
+    d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -443,6 +457,9 @@ struct PackedHost {
     int wide_depth = 0;       // wide levels of the TLAS + of the deepest BLAS (stack bound of the wide walker); 0: not built
     int n_tlasX = 0;          // records in tlasX (0: not built)
     int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
+    std::vector<int32_t> parent, nchild;     // TLAS, packed numbering: parent of a node (-1: none), children of an inner node
+    bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
+    int reach_leaves = 0;     // reachable TLAS leaves
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
 };
@@ -575,6 +592,27 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     alloc_nodes(nT, out.tlas);
     int32_t reachableT = -1;
     if (nT > 0) { reachableT = walk_order(s->tlasNodes, 0, nT, 0, perm); pack_range(s->tlasNodes, 0, nT, perm, out.tlas); }
+    {   // parents and child counts for the device refit: the children of an inner node are the chain left, left.skip, ...
+        // up to the node's own skip link (two nodes for both builders)
+        const size_t n = out.tlas.size();
+        out.parent.assign(n, -1); out.nchild.assign(n, 0);
+        auto cntq = [&](size_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.tlas[i].hi.w) >> 28); };
+        auto skipq = [&](size_t i) { return __builtin_bit_cast(int, out.tlas[i].hi.w) & kEnd; };
+        for (size_t i = 0; i < (size_t)nT; i++)
+        {
+            if (cntq(i) > 0) { if (reachableT < 0 || (int32_t)i < reachableT) out.reach_leaves++; continue; }
+            int c = __builtin_bit_cast(int, out.tlas[i].lo.w) & kEnd;
+            const int end = skipq(i);
+            int steps = 0;
+            while (c != kEnd && c != end)
+            {
+                if (c == 0 || out.parent[(size_t)c] != -1 || ++steps > 64) { out.refit_ok = false; break; }
+                out.parent[(size_t)c] = (int32_t)i; out.nchild[i]++;
+                c = skipq((size_t)c);
+            }
+        }
+        if (nT == 0) out.refit_ok = false;
+    }
     alloc_nodes(nB, out.blas);
     {
         // every instance owns the node range [blasRoot, blasRoot + blasNodeCount); each distinct range is renumbered
@@ -1159,6 +1197,14 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->small_scene = (s->n_tlasNodes + s->n_blasNodes) <= kSmallSceneNodes;
     c->flat_leaves = ph.n_flat;
     c->wide_depth = ph.wide_depth;
+    c->refit_ok = ph.refit_ok && ph.ok;
+    c->feat_alpha = (ph.feat & 2) != 0;
+    c->n_inst = s->n_instances; c->n_tlas = s->n_tlasNodes; c->n_slots = s->n_tlasInstanceIndices; c->n_blas = s->n_blasNodes;
+    c->tlas_leaves = ph.reach_leaves;
+    c->tlas_on_device = false;
+    // room for a TLAS rebuilt on the device over all instances (leaves of two: hrt_bvh.hpp)
+    const int64_t capT = std::max<int64_t>(std::max<int64_t>(s->n_tlasNodes, 2 * ((s->n_instances + 1) / 2) - 1), 1);
+    const int64_t capTI = std::max<int64_t>(std::max<int64_t>(s->n_tlasInstanceIndices, s->n_instances), 1);
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
     for (DeviceState& d : c->dev)
@@ -1169,7 +1215,8 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         {
             int64_t n = cnt[i] > 0 ? cnt[i] : 1;       // AllocateOrEmpty: empty -> 1 zeroed element
             size_t bytes = (size_t)n * kSceneElem[i];
-            HIPCHK(c, hipMalloc(&d.scene[i], bytes));
+            const size_t room = i == 0 ? (size_t)capT * kSceneElem[0] : (i == 1 ? (size_t)capTI * kSceneElem[1] : bytes);
+            HIPCHK(c, hipMalloc(&d.scene[i], std::max(bytes, room)));
             if (cnt[i] > 0) HIPCHK(c, hipMemcpyAsync(d.scene[i], src[i], bytes, hipMemcpyHostToDevice, d.stream));
             else if (i == 0) HIPCHK(c, hipMemcpyAsync(d.scene[i], &emptyTlas, bytes, hipMemcpyHostToDevice, d.stream));
             else HIPCHK(c, hipMemsetAsync(d.scene[i], 0, bytes, d.stream));
@@ -1188,10 +1235,30 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         const void* psrc[7] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), ph.wide.data(), ph.tlasX.data()};
         const size_t pbytes[7] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
                                   ph.flat.size() * sizeof(NodeQ), ph.wide.size() * sizeof(WNode), ph.tlasX.size() * sizeof(NodeQ)};
+        const size_t proom[7] = {(size_t)capT * sizeof(NodeQ), (size_t)capTI * sizeof(FInst), 0, 0, (size_t)kFlatMaxLeaves * sizeof(NodeQ), 0,
+                                 (size_t)(capT + capTI) * sizeof(NodeQ)};
         for (int i = 0; i < 7; i++)
         {
-            HIPCHK(c, hipMalloc(&d.packed[i], pbytes[i]));
+            HIPCHK(c, hipMalloc(&d.packed[i], std::max(pbytes[i], proom[i])));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
+        }
+        {   // maintenance arrays of the device-side TLAS update
+            const size_t ab[9] = {(size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, 16, 16, (size_t)capT * 4};
+            for (int i = 0; i < 9; i++) { HIPCHK(c, hipMalloc(&d.tlaux[i], ab[i])); HIPCHK(c, hipMemsetAsync(d.tlaux[i], 0, ab[i], d.stream)); }
+            if (!ph.parent.empty())
+            {
+                HIPCHK(c, hipMemcpyAsync(d.tlaux[0], ph.parent.data(), std::min(ph.parent.size(), (size_t)capT) * 4, hipMemcpyHostToDevice, d.stream));
+                HIPCHK(c, hipMemcpyAsync(d.tlaux[1], ph.nchild.data(), std::min(ph.nchild.size(), (size_t)capT) * 4, hipMemcpyHostToDevice, d.stream));
+            }
+            TlasDevice& T = d.tl;
+            T = TlasDevice{};
+            T.tlasNodes = (hrt_bvh_node*)d.scene[0]; T.tlasInst = (int32_t*)d.scene[1]; T.instances = (hrt_instance*)d.scene[2];
+            T.blasNodes = (const hrt_bvh_node*)d.scene[3]; T.spherePrimIdx = (const int32_t*)d.scene[4]; T.spheres = (const hrt_sphere*)d.scene[5];
+            T.tlas = (NodeQ*)d.packed[0]; T.finst = (FInst*)d.packed[1]; T.tlasX = (NodeQ*)d.packed[6]; T.flat = (NodeQ*)d.packed[4];
+            T.parent = (int*)d.tlaux[0]; T.nchild = (int*)d.tlaux[1]; T.arrive = (int*)d.tlaux[2]; T.nidx = (int*)d.tlaux[3]; T.lidx = (int*)d.tlaux[4];
+            T.sa = (float*)d.tlaux[5]; T.flags = (int*)d.tlaux[6]; T.cost = (float*)d.tlaux[7]; T.saBase = (float*)d.tlaux[8];
+            T.nI = (int)s->n_instances; T.nT = (int)s->n_tlasNodes; T.nTI = (int)s->n_tlasInstanceIndices;
+            T.capT = (int)capT; T.capTI = (int)capTI; T.flatMax = kFlatMaxLeaves;
         }
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
@@ -1201,6 +1268,158 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;
+    return HRT_OK;
+}
+
+namespace {
+
+constexpr float kAutoRebuildGrowth = 1.5f;     // HRT_REBUILD_AUTO: rebuild when the node boxes grew to this multiple of their built area (geometric mean)
+
+int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
+{
+    if (d.tlscratch) return HRT_OK;
+    TlasDevice& T = d.tl;
+    const size_t n = (size_t)std::max(T.nI, 1), L = (n + 1) / 2;
+    const size_t sortBytes = tlas_sort_temp_bytes((int)n);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t total = 3 * up(n * 4) + 7 * up(L * 4) + up(6 * 4) + up(sortBytes);
+    HIPCHK(c, hipMalloc(&d.tlscratch, total));
+    char* p = (char*)d.tlscratch;
+    auto take = [&](size_t b) { char* r = p; p += up(b); return (void*)r; };
+    T.keys = (unsigned*)take(n * 4); T.keysSorted = (unsigned*)take(n * 4); T.vals = (int*)take(n * 4);
+    T.rngA = (int*)take(L * 4); T.rngB = (int*)take(L * 4); T.split = (int*)take(L * 4); T.parInt = (int*)take(L * 4);
+    T.parLeaf = (int*)take(L * 4); T.idxInt = (int*)take(L * 4); T.idxLeaf = (int*)take(L * 4);
+    T.cbounds = (float*)take(6 * 4);
+    T.sortTmp = take(sortBytes); T.sortTmpBytes = sortBytes;
+    return HRT_OK;
+}
+
+} // namespace
+
+int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const hrt_affine3x4* xf, int32_t policy, hrt_bvh_update_stats* st)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: no scene uploaded");
+    if (n < 0 || (n > 0 && (!ids || !xf))) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: n instances need ids and transforms");
+    if (policy != HRT_REBUILD_AUTO && policy != HRT_REBUILD_FORCE_REFIT && policy != HRT_REBUILD_FORCE_REBUILD)
+        return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: unknown policy");
+    if (!c->packed_ok) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: the scene exceeds the limits of the packed layout");
+    if (c->n_inst <= 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: the scene has no instances");
+    {
+        std::vector<uint8_t> seen((size_t)c->n_inst, 0);
+        for (int i = 0; i < n; i++)
+        {
+            if (ids[i] < 0 || ids[i] >= c->n_inst) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id out of range");
+            if (seen[(size_t)ids[i]]++) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id listed twice");
+        }
+    }
+    if (policy != HRT_REBUILD_FORCE_REBUILD && !c->refit_ok && !c->tlas_on_device)
+    {
+        if (policy == HRT_REBUILD_FORCE_REFIT)
+            return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: this TLAS cannot be refitted (a node has several parents or more than 64 children); use HRT_REBUILD_FORCE_REBUILD");
+        policy = HRT_REBUILD_FORCE_REBUILD;
+    }
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
+    hrt_bvh_update_stats out; std::memset(&out, 0, sizeof(out));
+    bool first = true;
+    for (DeviceState& d : c->dev)
+    {
+        HIPCHK(c, hipSetDevice(d.device_id));
+        TlasDevice& T = d.tl;
+        hipEvent_t e0 = d.ev[0][0], e1 = d.ev[0][1];
+        HIPCHK(c, hipEventRecord(e0, d.stream));
+        int h_flags[4]; float h_cost[2] = {1.f, 0.f};
+        auto finish_and_read = [&]() -> int {
+            HIPCHK(c, tlas_finish(T, d.stream));
+            HIPCHK(c, hipMemcpyAsync(h_flags, T.flags, sizeof(h_flags), hipMemcpyDeviceToHost, d.stream));
+            HIPCHK(c, hipMemcpyAsync(h_cost, T.cost, sizeof(h_cost), hipMemcpyDeviceToHost, d.stream));
+            HIPCHK(c, hipStreamSynchronize(d.stream));
+            return HRT_OK;
+        };
+        auto keep_as_base = [&]() -> int {
+            HIPCHK(c, hipMemcpyAsync(T.saBase, T.sa, (size_t)T.nT * 4, hipMemcpyDeviceToDevice, d.stream));
+            d.tlas_base_valid = true;
+            return HRT_OK;
+        };
+        if (!d.tlas_base_valid && policy != HRT_REBUILD_FORCE_REBUILD)
+        {   // node areas of the tree as it was built: taken once, before anything moves
+            HIPCHK(c, tlas_finish(T, d.stream));
+            if ((rc = keep_as_base()) != HRT_OK) return rc;
+        }
+        void* staged = nullptr;
+        if (n > 0)
+        {
+            const size_t idb = ((size_t)n * 4 + 63) & ~(size_t)63;
+            HIPCHK(c, hipMalloc(&staged, idb + (size_t)n * sizeof(hrt_affine3x4)));
+            HIPCHK(c, hipMemcpyAsync(staged, ids, (size_t)n * 4, hipMemcpyHostToDevice, d.stream));
+            HIPCHK(c, hipMemcpyAsync((char*)staged + idb, xf, (size_t)n * sizeof(hrt_affine3x4), hipMemcpyHostToDevice, d.stream));
+            HIPCHK(c, tlas_set_transforms(T, (const int32_t*)staged, (const hrt_affine3x4*)((char*)staged + idb), n, d.stream));
+        }
+        int action = policy == HRT_REBUILD_FORCE_REBUILD ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT;
+        float growthRefit = 0.f;
+        if (action == HRT_REBUILD_FORCE_REFIT)
+        {
+            if ((rc = finish_and_read()) != HRT_OK) return rc;
+            growthRefit = h_cost[0];
+            if (policy == HRT_REBUILD_AUTO && growthRefit > kAutoRebuildGrowth) action = HRT_REBUILD_FORCE_REBUILD;
+        }
+        if (action == HRT_REBUILD_FORCE_REBUILD)
+        {
+            if ((rc = ensure_lbvh_scratch(c, d)) != HRT_OK) return rc;
+            HIPCHK(c, tlas_rebuild_topology(T, d.stream));
+            if ((rc = finish_and_read()) != HRT_OK) return rc;
+            if ((rc = keep_as_base()) != HRT_OK) return rc;
+            h_cost[0] = 1.f;                                            // as built
+        }
+        HIPCHK(c, hipEventRecord(e1, d.stream));
+        HIPCHK(c, hipEventSynchronize(e1));
+        if (staged) HIPCHK(c, hipFree(staged));
+        // the walkers' view of the tree
+        const bool general = h_flags[0] != 0;
+        d.dpacked.nTlas = T.nT;
+        const bool walkOrder = action == HRT_REBUILD_FORCE_REBUILD || c->tlas_on_device || !getenv("HRT_BUILDER_ORDER");
+        const bool inl = !general && !c->feat_alpha && walkOrder && (int64_t)T.nT + T.nTI < kEnd && !getenv("HRT_NO_INLINE_INSTANCES");
+        d.dpacked.tlasX = inl ? (const NodeQ*)d.packed[6] : nullptr;
+        d.dpacked.nTlasX = inl ? T.nT + T.nTI : 0;
+        d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = kWNone;
+        if (first)
+        {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+            out.action = action; out.tlas_nodes = T.nT; out.tlas_slots = T.nTI; out.general_instances = general ? 1 : 0;
+            out.growth_refit = growthRefit; out.growth_final = h_cost[0]; out.sah_cost = h_cost[1]; out.device_ms = ms;
+            if (action == HRT_REBUILD_FORCE_REBUILD) { c->tlas_leaves = (T.nI + 1) / 2; c->refit_ok = true; }
+            c->packed_feat = c->feat_alpha ? 3 : (general ? 1 : 0);
+            c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
+            c->n_tlas = T.nT; c->n_slots = T.nTI;
+            c->small_scene = (c->n_tlas + c->n_blas) <= kSmallSceneNodes;
+            c->wide_depth = 0;                       // the 4-wide collapse is not maintained on the device
+            c->tlas_on_device = true;
+            first = false;
+        }
+    }
+    if (st) *st = out;
+    return HRT_OK;
+}
+
+int hrt_scene_download_tlas(hrt_ctx* c, int dev, hrt_bvh_node* nodes, int64_t capN, int32_t* idx, int64_t capI, hrt_instance* inst, int64_t capInst, int64_t* counts)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_download_tlas: no scene uploaded");
+    if (dev < 0 || dev >= (int)c->dev.size()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_tlas: device slot out of range");
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
+    DeviceState& d = c->dev[(size_t)dev];
+    const int64_t have[3] = {c->n_tlas, c->n_slots, c->n_inst};
+    if (counts) { counts[0] = have[0]; counts[1] = have[1]; counts[2] = have[2]; }
+    if ((nodes && capN < have[0]) || (idx && capI < have[1]) || (inst && capInst < have[2]))
+        return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_tlas: destination too small");
+    HIPCHK(c, hipSetDevice(d.device_id));
+    if (nodes && have[0] > 0) HIPCHK(c, hipMemcpyAsync(nodes, d.scene[0], (size_t)have[0] * sizeof(hrt_bvh_node), hipMemcpyDeviceToHost, d.stream));
+    if (idx && have[1] > 0) HIPCHK(c, hipMemcpyAsync(idx, d.scene[1], (size_t)have[1] * 4, hipMemcpyDeviceToHost, d.stream));
+    if (inst && have[2] > 0) HIPCHK(c, hipMemcpyAsync(inst, d.scene[2], (size_t)have[2] * sizeof(hrt_instance), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(c, hipStreamSynchronize(d.stream));
     return HRT_OK;
 }
 

@@ -50,6 +50,9 @@ def lib():
         L.hrt_last_error.argtypes = [C.c_void_p]
         L.hrt_last_error.restype = C.c_char_p
         L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+        L.hrt_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+        L.hrt_scene_download_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                              C.POINTER(C.c_int64)]
         L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
         L.hrt_synchronize.argtypes = [C.c_void_p, C.POINTER(T.Stats)]
         L.hrt_present.argtypes = [C.c_void_p, C.POINTER(T.PresentParams), C.c_void_p]
@@ -83,6 +86,7 @@ def lib():
         L.hrth_scene_load_obj_instance.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(T.Affine3x4), C.c_float]
         L.hrth_last_error.restype = C.c_char_p
         L.hrth_scene_rebuild_tlas.argtypes = [C.c_void_p]
+        L.hrth_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
         L.hrth_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrth_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
         L.hrth_camera_lookat.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
@@ -280,6 +284,12 @@ class Scene:
         """Scene.RebuildTLAS (Scene.cs:358-368)."""
         lib().hrth_scene_rebuild_tlas(self._h)
 
+    def set_instance_transform(self, inst_id, xform):
+        """Moves an instance of the host scene (records re-derived as at creation); follow with rebuild_tlas() + commit,
+        or mirror the move on the device with RTRenderer.update_instances."""
+        if lib().hrth_scene_set_instance_transform(self._h, int(inst_id), C.byref(xform)) != 0:
+            raise IndexError("instance id out of range")
+
     def desc(self):
         d = T.SceneDesc()
         lib().hrth_scene_get_desc(self._h, C.byref(d))
@@ -346,6 +356,31 @@ class RTRenderer:
             self.scene = scene_or_desc
             d = scene_or_desc.desc()
         self._check(lib().hrt_scene_upload(self._ctx, C.byref(d)))
+
+    def update_instances(self, ids, transforms, policy=T.REBUILD_AUTO):
+        """BvhManager.BuildOrRefit(scene, policy) for moved instances, on the device (hrt_scene_update_instances).
+        ids: instance ids; transforms: Affine3x4 objects or an (n, 12) float32 array, row-major 3x4.  Returns BvhUpdateStats."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        if len(transforms) and isinstance(transforms[0], T.Affine3x4):
+            xf = np.array([[getattr(a, f"m{r}{c}") for r in range(3) for c in range(4)] for a in transforms], dtype=np.float32)
+        else:
+            xf = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 12)
+        if xf.shape[0] != ids.size:
+            raise ValueError("one transform per instance id")
+        st = T.BvhUpdateStats()
+        self._check(lib().hrt_scene_update_instances(self._ctx, ids.ctypes.data if ids.size else None, ids.size,
+                                                     xf.ctypes.data if ids.size else None, policy, C.byref(st)))
+        return st
+
+    def download_tlas(self, slot=0):
+        """(tlasNodes, tlasInstanceIndices, instances) of the TLAS in use, as ctypes arrays in the reference's layout."""
+        cnt = (C.c_int64 * 3)()
+        self._check(lib().hrt_scene_download_tlas(self._ctx, slot, None, 0, None, 0, None, 0, cnt))
+        nodes = (T.BvhNode * max(1, cnt[0]))()
+        idx = (C.c_int32 * max(1, cnt[1]))()
+        inst = (T.InstanceRecord * max(1, cnt[2]))()
+        self._check(lib().hrt_scene_download_tlas(self._ctx, slot, nodes, cnt[0], idx, cnt[1], inst, cnt[2], cnt))
+        return nodes, idx, inst, tuple(cnt)
 
     def set_sun_params(self, speed_rad_per_sec, elevation_rad):
         """RTRenderer.SetSunParams (RTRenderer.cs:99-103)."""

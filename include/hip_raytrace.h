@@ -167,6 +167,45 @@ const char* hrt_last_error(hrt_ctx* ctx);      /* ctx may be NULL: last error of
 
 int  hrt_scene_upload(hrt_ctx* ctx, const hrt_scene_desc* scene);
 
+/* ---- moving instances of the committed scene: BvhManager.BuildOrRefit(scene, policy) (BvhManager.cs:13-27).
+ * The reference declares the policy and ignores it: Commit re-runs RebuildTLAS on the host (Scene.cs:358-368)
+ * and re-uploads all fifteen arrays (Scene.cs:258-279).  Here the scene stays on the device:
+ *   - objectToWorld of instance instance_ids[k] becomes objectToWorld[k]; worldToObject, uniformScale and the
+ *     world bounds are derived from it exactly as Scene.cs does (InvertRigidOrUniform :616-638, TransformAABB
+ *     :560-580 of the box of the instance's BLAS root node); instance_ids must be distinct;
+ *   - HRT_REBUILD_FORCE_REFIT keeps the TLAS topology and recomputes every box bottom-up;
+ *   - HRT_REBUILD_FORCE_REBUILD builds a new TLAS over ALL instances (as RebuildTLAS does) with a Morton-order
+ *     LBVH, leaves of <= 2 instances;
+ *   - HRT_REBUILD_AUTO refits, and rebuilds if the boxes of the refitted tree have grown, in the geometric mean
+ *     over all nodes, to more than 1.5 x the surface area they had when the tree was last built (uploaded or
+ *     rebuilt): a measure neither one far-flung instance nor one huge instance dominates.
+ * n may be 0 (re-derive / rebuild only).  Blocking; every device of the context is updated.  The TLAS of a scene
+ * updated this way is numbered in walk order; hrt_scene_download_tlas returns it in the reference's layout.
+ * A different tree visits the same primitives in another order: results change only where two primitives are
+ * hit at bit-equal distance (DESIGN.md "inner nodes only accelerate"). */
+enum hrt_rebuild_policy { HRT_REBUILD_AUTO = 0, HRT_REBUILD_FORCE_REFIT = 1, HRT_REBUILD_FORCE_REBUILD = 2 };
+
+typedef struct hrt_bvh_update_stats {
+    int32_t action;           /* HRT_REBUILD_FORCE_REFIT or HRT_REBUILD_FORCE_REBUILD: what was done          */
+    int32_t tlas_nodes;       /* nodes of the TLAS now in use                                                  */
+    int32_t tlas_slots;       /* entries of its instance index list                                            */
+    int32_t general_instances;/* 1 if a leaf slot holds an instance that needs the ray transform               */
+    float   growth_refit;     /* after the refit: geometric mean over the nodes of area / area at the last build (0: no refit) */
+    float   growth_final;     /* the same for the tree now in use (1 after a rebuild)                          */
+    float   sah_cost;         /* of the tree now in use: sum(area x (leaf ? count : 1)) / area(root)            */
+    float   device_ms;        /* HIP-event time of the device work on device slot 0                            */
+} hrt_bvh_update_stats;
+
+int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32_t n, const hrt_affine3x4* objectToWorld,
+                                int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
+
+/* Copies the TLAS in use on device slot `dev`, in the reference's layout, and the instance records to the host
+ * (any pointer may be NULL).  counts[3] (may be NULL) receives the element counts {tlasNodes, tlasInstanceIndices,
+ * instances}; an array is copied only if its capacity (in elements) is large enough, else HRT_ERR_INVALID_ARG. */
+int  hrt_scene_download_tlas(hrt_ctx* ctx, int dev, hrt_bvh_node* tlasNodes, int64_t cap_nodes,
+                             int32_t* tlasInstanceIndices, int64_t cap_indices, hrt_instance* instances, int64_t cap_instances,
+                             int64_t* counts);
+
 int  hrt_render_frame(hrt_ctx* ctx, const hrt_frame_params* params,
                       const hrt_render_opts* opts,      /* may be NULL */
                       const hrt_outputs* outputs,       /* may be NULL: leave results on device */

@@ -82,6 +82,10 @@ void  hrth_image_free(uint8_t* bgra);
 int   hrth_scene_load_obj_instance(void* scene, const char* objPath, const hrt_affine3x4* objectToWorld, float uniformScale);
 const char* hrth_last_error(void);
 void  hrth_scene_rebuild_tlas(void* scene);
+/* moves an instance of the host scene: objectToWorld, worldToObject, uniformScale and the world bounds as the
+ * instance builders derive them (Scene.cs:395-402, 236-252); follow with hrth_scene_rebuild_tlas (host rebuild)
+ * or mirror the move on the device with hrt_scene_update_instances.  0 ok, -1 bad id. */
+int   hrth_scene_set_instance_transform(void* scene, int instance_id, const hrt_affine3x4* objectToWorld);
 void  hrth_scene_get_desc(void* scene, hrt_scene_desc* out);
 
 void  hrth_camera_create(int width, int height, float fovDegrees, hrt_camera* out);

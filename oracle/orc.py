@@ -43,6 +43,7 @@ def lib():
                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
         L.orc_scene_rebuild_tlas.argtypes = [C.c_void_p]
+        L.orc_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
         L.orc_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.orc_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
         L.orc_camera_lookat.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
@@ -162,6 +163,11 @@ class OrcScene:
 
     def rebuild_tlas(self):
         lib().orc_scene_rebuild_tlas(self.h)
+
+    def set_instance_transform(self, inst_id, xform):
+        """Moves an instance (records re-derived as at creation); call rebuild_tlas() afterwards as Commit would."""
+        if lib().orc_scene_set_instance_transform(self.h, int(inst_id), C.byref(xform)) != 0:
+            raise IndexError("instance id out of range")
 
     def desc(self):
         d = T.SceneDesc()

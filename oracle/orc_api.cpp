@@ -335,6 +335,13 @@ int orc_scene_load_mesh_instance(void* s_, const hrt_float3* pos, int nPos, cons
     return (int)s->_hInstances.size() - 1;
 }
 void orc_scene_rebuild_tlas(void* s) { static_cast<Scene*>(s)->RebuildTLAS(); }
+int orc_scene_set_instance_transform(void* s, int id, const hrt_affine3x4* m)
+{
+    Scene* sc = static_cast<Scene*>(s);
+    if (!m || id < 0 || id >= (int)sc->_hInstances.size()) return -1;
+    sc->SetInstanceTransform(id, *m);
+    return 0;
+}
 void orc_scene_get_desc(void* s, hrt_scene_desc* d) { static_cast<Scene*>(s)->GetDesc(*d); }
 
 // ------------------------------------------------------------------ presentation kernels

@@ -749,6 +749,25 @@ struct Scene {
         return invM;
     }
 
+    // A moved instance: what BuildSphereInstance / LoadObjInstance would have written for this objectToWorld
+    // (Scene.cs:395-402, :236-252), with the box of the instance's BLAS root node as the object-space bounds
+    // (both builders make the root the union of all primitive boxes, which is what those two functions transform).
+    void SetInstanceTransform(int id, const hrt_affine3x4& objectToWorld)
+    {
+        hrt_instance& inst = _hInstances[(size_t)id];
+        Float3 bmin(0.f, 0.f, 0.f), bmax(0.f, 0.f, 0.f);
+        if (inst.blasNodeCount > 0) { bmin = Float3(_hBLASNodes[(size_t)inst.blasRoot].boundsMin); bmax = Float3(_hBLASNodes[(size_t)inst.blasRoot].boundsMax); }
+        Float3 wmin, wmax;
+        TransformAABB(objectToWorld, bmin, bmax, wmin, wmax);
+        float uniScale;
+        hrt_affine3x4 worldToObject = InvertRigidOrUniform(objectToWorld, uniScale);
+        inst.objectToWorld = objectToWorld;
+        inst.worldToObject = worldToObject;
+        inst.uniformScale = uniScale;
+        inst.worldBoundsMin = wmin;
+        inst.worldBoundsMax = wmax;
+    }
+
     void GetDesc(hrt_scene_desc& d) const
     {
         std::memset(&d, 0, sizeof(d));

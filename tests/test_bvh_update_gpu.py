@@ -1,0 +1,274 @@
+"""Device-side TLAS maintenance (hrt_scene_update_instances = BvhManager.BuildOrRefit with the
+RebuildPolicy the reference declares and ignores, BvhManager.cs:13-27).
+
+What is checked, all bit-exact:
+  * instance records re-derived on the device == the oracle's restatement of InvertRigidOrUniform / TransformAABB;
+  * a refit == the same topology with every box recomputed bottom-up (numpy restatement below), a refit without any
+    move == the uploaded tree;
+  * a rebuilt tree is a valid TLAS (every instance in exactly one leaf, <= 2 per leaf, every box the union of its
+    children, every node on the walk) and the same moves give the same tree again;
+  * frames rendered on the device-maintained tree == the oracle rendering the DOWNLOADED arrays, in every kernel
+    organisation, and == the frame of the same scene rebuilt on the host wherever the reference's picture does not depend on the
+    tree (translated / shrunk instances, no exact hit-distance ties in these scenes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ilgpu_raytracing_amd import _types as T, engine, scenes
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CFG_SPH = scenes.Config("upd", 0, 0, 0, (0.0, 3.0, 9.0), (0.0, 0.8, 0.0))
+CFG_ROT = scenes.Config("rot", 0, 0, 0, (0.4, 1.6, 4.6), (0.0, 0.8, 0.0))
+
+
+def _spheres(b):
+    scenes.build_random_spheres(b, 60, extent=4.0)
+
+
+SCENES = {
+    "sphere_instances": (_spheres, CFG_SPH, 128, 80, 2),
+    "cornell_flat_leaves": (scenes.build_config2, scenes.CONFIGS[2], 128, 72, 2),
+    "rotated_mesh_and_sets": (scenes.build_rotated_instances_scene, CFG_ROT, 128, 80, 2),
+}
+MODES = {"auto": T.FLAG_COUNTERS, "auto_production": 0, "stream_production": T.FLAG_STREAMED, "mega_production": T.FLAG_MEGAKERNEL,
+         "stream_reflayout": T.FLAG_COUNTERS | T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT}
+
+
+def _moves(n_inst, kind):
+    """instance ids + transforms.  kind: 'rigid' = rotation, uniform scale up to 1.2 and translation; 'translate' =
+    translation with a uniform scale <= 1; 'identity' = nothing really moves."""
+    ids = [i for i in range(n_inst) if i % 3 != 0][:24]          # instance 0 (the ground) stays
+    xfs = []
+    for k, i in enumerate(ids):
+        if kind == "identity":
+            xfs.append(T.identity_affine())
+        elif kind == "translate":
+            xfs.append(scenes.rotation_affine("y", 0.0, 1.0 if k % 3 else 0.75, (0.3 * (k % 4) - 0.4, 0.1 * (k % 3), 0.25 * (k % 5) - 0.5)))
+        elif k % 2 == 0:
+            xfs.append(scenes.rotation_affine("xyz"[k % 3], 17.0 * k, 1.0 + 0.05 * (k % 5), (0.3 * (k % 4) - 0.4, 0.1 * (k % 3), 0.25 * (k % 5) - 0.5)))
+        else:
+            xfs.append(scenes.rotation_affine("y", 0.0, 1.0, (0.15 * k - 1.0, 0.05 * k, -0.1 * k)))
+    return ids, xfs
+
+
+def _as_np(ct_array, n, t):
+    return np.frombuffer(ct_array, dtype=T.np_dtype(t), count=n).copy()
+
+
+def _download(r):
+    nodes, idx, inst, cnt = r.download_tlas()
+    return _as_np(nodes, cnt[0], T.BvhNode), np.frombuffer(idx, dtype=np.int32, count=cnt[1]).copy(), _as_np(inst, cnt[2], T.InstanceRecord)
+
+
+def _walk(nodes, idx):
+    """The tree as the walk sees it: [(boundsMin, boundsMax, tuple(instances of a leaf) or None)] in walk order."""
+    out, cur, guard = [], 0 if len(nodes) else -1, 0
+    while cur != -1:
+        n = nodes[cur]
+        leaf = n["count"] > 0
+        out.append((n["boundsMin"].tobytes(), n["boundsMax"].tobytes(), tuple(int(v) for v in idx[n["first"]:n["first"] + n["count"]]) if leaf else None))
+        cur = int(n["skipIndex"]) if leaf else int(n["left"])
+        guard += 1
+        assert guard <= len(nodes), "walk does not end"
+    return out
+
+
+def _refit_numpy(nodes, idx, inst):
+    """Same topology, every box recomputed: leaves from their instances' world bounds, inner nodes from their children
+    (left, then the skip chain up to the node's own skip link)."""
+    nodes = nodes.copy()
+
+    def rec(i):
+        n = nodes[i]
+        if n["count"] > 0:
+            ids = idx[n["first"]:n["first"] + n["count"]]
+            lo = np.min(np.stack([np.array(list(inst[j]["worldBoundsMin"].tolist()), np.float32) for j in ids]), axis=0)
+            hi = np.max(np.stack([np.array(list(inst[j]["worldBoundsMax"].tolist()), np.float32) for j in ids]), axis=0)
+        else:
+            los, his, c = [], [], int(n["left"])
+            while c != -1 and c != int(n["skipIndex"]):
+                a, b = rec(c)
+                los.append(a); his.append(b)
+                c = int(nodes[c]["skipIndex"])
+            lo, hi = np.min(np.stack(los), axis=0), np.max(np.stack(his), axis=0)
+        for k, f in enumerate("XYZ"):
+            nodes[i]["boundsMin"][f] = lo[k]
+            nodes[i]["boundsMax"][f] = hi[k]
+        return lo, hi
+
+    if len(nodes):
+        rec(0)
+    return nodes
+
+
+def _desc_with_tlas(base_desc, nodes, idx, inst):
+    """base_desc with the three TLAS-side arrays replaced (numpy structured arrays kept alive by the caller)."""
+    d = T.SceneDesc()
+    C.memmove(C.byref(d), C.byref(base_desc), C.sizeof(d))
+    d.tlasNodes = C.cast(nodes.ctypes.data, C.POINTER(T.BvhNode)); d.n_tlasNodes = len(nodes)
+    d.tlasInstanceIndices = C.cast(idx.ctypes.data, C.POINTER(C.c_int32)); d.n_tlasInstanceIndices = len(idx)
+    d.instances = C.cast(inst.ctypes.data, C.POINTER(T.InstanceRecord)); d.n_instances = len(inst)
+    return d
+
+
+def _oracle_render(orc, desc, cfg, w, h, spp):
+    p = scenes.frame_params(cfg, *H.host_funcs("orc", orc), width=w, height=h, spp=spp)
+    arrs, o = T.alloc_outputs(w, h)
+    st = orc.render_frame(desc, p, o, None)
+    return arrs, st
+
+
+def _gpu_render(r, cfg, w, h, spp, flags):
+    r.reset_history()
+    p = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+    arrs, o = T.alloc_outputs(w, h)
+    st = r.render_params(p, o, flags=flags)
+    return arrs, st
+
+
+def _check_frames(orc, r, desc, cfg, w, h, spp):
+    ref, ost = _oracle_render(orc, desc, cfg, w, h, spp)
+    for mode, flags in MODES.items():
+        got, gst = _gpu_render(r, cfg, w, h, spp, flags)
+        H.assert_outputs_equal(ref, got)
+        if flags & T.FLAG_COUNTERS:
+            for i in range(2):
+                assert gst.k[i].as_dict() == ost.k[i].as_dict(), (mode, i)
+    return ref
+
+
+def _check_valid_tlas(nodes, idx, inst):
+    n_inst = len(inst)
+    assert sorted(idx.tolist()) == list(range(n_inst)), "every instance in exactly one leaf slot"
+    leaves = (n_inst + 1) // 2
+    assert len(nodes) == 2 * leaves - 1
+    walk = _walk(nodes, idx)
+    assert len(walk) == len(nodes), "every node is on the walk"
+    assert all(len(l) <= 2 for _, _, l in walk if l is not None)
+    assert sum(len(l) for _, _, l in walk if l is not None) == n_inst
+    again = _refit_numpy(nodes, idx, inst)
+    assert nodes.tobytes() == again.tobytes(), "every box is the union of what it holds"
+    # walk-order numbering: the left child follows its parent
+    for i, n in enumerate(nodes):
+        if n["count"] == 0:
+            assert n["left"] == i + 1 and n["right"] == nodes[i + 1]["skipIndex"]
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_refit_without_moves_reproduces_the_uploaded_tree(orc, renderer, name):
+    builder, cfg, w, h, spp = SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    host = s.arrays()
+    st = renderer.update_instances([], [], T.REBUILD_FORCE_REFIT)
+    assert st.action == T.REBUILD_FORCE_REFIT and st.tlas_nodes == len(host["tlasNodes"])
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == host["instances"].tobytes()
+    assert idx.tolist() == host["tlasInstanceIndices"].tolist()
+    assert _walk(nodes, idx) == _walk(host["tlasNodes"], host["tlasInstanceIndices"])
+    so = orc.OrcScene(); builder(so)
+    _check_frames(orc, renderer, so.desc(), cfg, w, h, spp)
+
+
+@pytest.mark.parametrize("kind", ["rigid", "identity"])
+@pytest.mark.parametrize("name", list(SCENES))
+def test_refit_after_moves(orc, renderer, name, kind):
+    builder, cfg, w, h, spp = SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    so = orc.OrcScene(); builder(so)
+    ids, xfs = _moves(len(so.arrays()["instances"]), kind)
+    st = renderer.update_instances(ids, xfs, T.REBUILD_FORCE_REFIT)
+    assert st.action == T.REBUILD_FORCE_REFIT
+    for i, m in zip(ids, xfs):
+        so.set_instance_transform(i, m)
+        s.set_instance_transform(i, m)
+    oa = so.arrays()
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == oa["instances"].tobytes(), "instance records derived on the device"
+    assert inst.tobytes() == s.arrays()["instances"].tobytes(), "... and by the library's host scene"
+    want = _refit_numpy(oa["tlasNodes"], oa["tlasInstanceIndices"], oa["instances"])
+    assert _walk(nodes, idx) == _walk(want, oa["tlasInstanceIndices"])
+    general = any(not np.array_equal(np.frombuffer(bytes(m), np.float32), np.frombuffer(bytes(T.identity_affine()), np.float32)) for m in xfs) \
+        or name == "rotated_mesh_and_sets"
+    assert st.general_instances == (1 if general else 0)
+    _check_frames(orc, renderer, _desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+
+
+@pytest.mark.parametrize("kind", ["rigid", "translate", "identity"])
+@pytest.mark.parametrize("name", list(SCENES))
+def test_rebuild_on_the_device(orc, renderer, name, kind):
+    builder, cfg, w, h, spp = SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    so = orc.OrcScene(); builder(so)
+    ids, xfs = _moves(len(so.arrays()["instances"]), kind)
+    st = renderer.update_instances(ids, xfs, T.REBUILD_FORCE_REBUILD)
+    assert st.action == T.REBUILD_FORCE_REBUILD and st.sah_cost > 0.0 and st.growth_final == 1.0 and st.growth_refit == 0.0
+    for i, m in zip(ids, xfs):
+        so.set_instance_transform(i, m)
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == so.arrays()["instances"].tobytes()
+    _check_valid_tlas(nodes, idx, inst)
+    assert st.tlas_nodes == len(nodes) and st.tlas_slots == len(idx)
+    ref = _check_frames(orc, renderer, _desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+    # The same scene rebuilt on the host as Commit would (RebuildTLAS, Scene.cs:358-368): another tree, the same picture --
+    # where the reference's picture does not depend on the tree.  It does for two of its quirks:
+    # InvertRigidOrUniform writes the normalised columns of a rotation back as columns, i.e. not its inverse
+    # (Scene.cs:628-631), so a rotated instance is seen somewhere else than its TLAS box; and TraceClosest prunes TLAS
+    # boxes with closestT = tObj / uniformScale (SceneDeviceViews.cs:46-47,67), which for a scale > 1 lies before the box
+    # the hit is in.  Translations and scales <= 1 are safe.
+    if kind != "rigid" and name != "rotated_mesh_and_sets":
+        so.rebuild_tlas()
+        host, _ = _oracle_render(orc, so.desc(), cfg, w, h, spp)
+        H.assert_outputs_equal(host, ref)
+    # deterministic: the same moves again give the same tree
+    renderer.update_instances(ids, xfs, T.REBUILD_FORCE_REBUILD)
+    nodes2, idx2, inst2 = _download(renderer)
+    assert nodes2.tobytes() == nodes.tobytes() and idx2.tolist() == idx.tolist() and inst2.tobytes() == inst.tobytes()
+    # and a refit of the rebuilt tree keeps it
+    st3 = renderer.update_instances([], [], T.REBUILD_FORCE_REFIT)
+    nodes3, idx3, _ = _download(renderer)
+    assert st3.action == T.REBUILD_FORCE_REFIT and nodes3.tobytes() == nodes.tobytes() and idx3.tolist() == idx.tolist()
+
+
+def test_auto_refits_small_moves_and_rebuilds_when_the_tree_degrades(orc, renderer):
+    builder, cfg, w, h, spp = SCENES["sphere_instances"]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    so = orc.OrcScene(); builder(so)
+    n = len(so.arrays()["instances"])
+    ids = list(range(1, n))
+    small = [scenes.rotation_affine("y", 0.0, 1.0, (0.01 * (i % 3), 0.0, 0.0)) for i in ids]
+    st = renderer.update_instances(ids, small, T.REBUILD_AUTO)
+    assert st.action == T.REBUILD_FORCE_REFIT and 0.9 < st.growth_refit <= 1.5 and st.growth_final == st.growth_refit
+    # every instance to the mirrored position: neighbours in the tree end up far apart
+    far = [scenes.rotation_affine("y", 0.0, 1.0, (((i * 7919) % 13) - 6.0, 0.0, ((i * 104729) % 11) - 5.0)) for i in ids]
+    st = renderer.update_instances(ids, far, T.REBUILD_AUTO)
+    assert st.action == T.REBUILD_FORCE_REBUILD and st.growth_refit > 1.5 and st.growth_final == 1.0
+    for i, m in zip(ids, far):
+        so.set_instance_transform(i, m)
+    nodes, idx, inst = _download(renderer)
+    _check_valid_tlas(nodes, idx, inst)
+    _check_frames(orc, renderer, _desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+
+
+def test_update_errors(renderer):
+    fresh = engine.RTRenderer([0])
+    try:
+        with pytest.raises(engine.HrtError, match="no scene"):
+            fresh.update_instances([], [], T.REBUILD_AUTO)
+    finally:
+        fresh.close()
+    s = engine.Scene(); scenes.build_config2(s); renderer.commit(s)
+    I = T.identity_affine()
+    with pytest.raises(engine.HrtError, match="out of range"):
+        renderer.update_instances([99], [I])
+    with pytest.raises(engine.HrtError, match="twice"):
+        renderer.update_instances([1, 1], [I, I])
+    with pytest.raises(engine.HrtError, match="policy"):
+        renderer.update_instances([1], [I], policy=7)
+    cnt = (C.c_int64 * 3)()
+    nodes = (T.BvhNode * 1)()
+    with pytest.raises(engine.HrtError, match="too small"):
+        renderer._check(engine.lib().hrt_scene_download_tlas(renderer._ctx, 0, nodes, 1, None, 0, None, 0, cnt))
+    assert cnt[0] > 1
