@@ -68,6 +68,13 @@ namespace ILGPU_Raytracing.Engine
         public int n_devices, counters_valid, frames, reserved;
     }
 
+    [StructLayout(LayoutKind.Sequential)]
+    public struct HrtBvhUpdateStats
+    {
+        public int action, tlas_nodes, tlas_slots, general_instances;
+        public float growth_refit, growth_final, sah_cost, device_ms;
+    }
+
     internal static unsafe class HipRaytrace
     {
         const string Lib = "hip_raytrace";        // libhip_raytrace.so
@@ -76,6 +83,9 @@ namespace ILGPU_Raytracing.Engine
         [DllImport(Lib)] public static extern void hrt_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr hrt_last_error(IntPtr ctx);
         [DllImport(Lib)] public static extern int hrt_scene_upload(IntPtr ctx, HrtSceneDesc* scene);
+        // BvhManager.BuildOrRefit(scene, policy) for moved instances: policy = (int)RebuildPolicy (Auto 0, ForceRefit 1, ForceRebuild 2)
+        [DllImport(Lib)] public static extern int hrt_scene_update_instances(IntPtr ctx, int* instanceIds, int n, Affine3x4* objectToWorld, int policy, HrtBvhUpdateStats* stats);
+        [DllImport(Lib)] public static extern int hrt_scene_download_tlas(IntPtr ctx, int dev, TLASNode* nodes, long capNodes, int* indices, long capIndices, InstanceRecord* instances, long capInstances, long* counts);
         [DllImport(Lib)] public static extern int hrt_render_frame(IntPtr ctx, HrtFrameParams* p, HrtRenderOpts* opts, HrtOutputs* outputs, HrtStats* stats);
         [DllImport(Lib)] public static extern int hrt_present(IntPtr ctx, HrtPresentParams* p, int* outColorHost);
         [DllImport(Lib)] public static extern int hrt_synchronize(IntPtr ctx, HrtStats* stats);

@@ -116,22 +116,37 @@ __global__ void __launch_bounds__(kBlock) k_leaf_slots(TlasDevice T)
 }
 
 // ------------------------------------------------------------------ boxes, bottom-up
-// One thread per node; leaves take the union of their instances' world bounds (BuildTLASNodeRecursive, Scene.cs:472-480)
-// and climb: the last child to arrive at an inner node unites the children (the chain left, left.skip, ... up to the
-// node's own skip link) and climbs on.  min / max are exact, so the order of arrival cannot change a bit.
+// One thread per node.  In walk-order numbering the subtree of node i is the index range [i, skip(i)), so a node whose
+// subtree has at most T.directMax nodes takes its box straight from the instances of the leaves in that range
+// (BuildTLASNodeRecursive's own loop over its items, Scene.cs:472-480) -- no ordering between threads at all for the
+// bottom five levels, which hold 31 of every 32 nodes.  Above that the boxes are united bottom-up: a finished node
+// reports to its parent, and the last child to arrive unites the children (the chain left, left.skip, ... up to the
+// parent's own skip link) and climbs on.  Release / acquire at agent scope costs an L2 write-back per step on a
+// multi-XCD part, which is why only one node in 32 takes part.  min / max are exact: no order can change a bit.
+HRT_D int subtree_size(const TlasDevice& T, int i)
+{
+    const int sk = node_skip(T.tlas, i);
+    return (sk == kEnd ? T.nT : sk) - i;
+}
+
 __global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= T.nT) return;
     NodeQ* nodes = T.tlas;
     const int cnt = node_cnt(nodes, i);
-    if (cnt == 0) return;
-    const int first = node_link(nodes, i);
+    const int size = cnt > 0 ? 1 : (T.directMax > 1 ? subtree_size(T, i) : T.nT + 1);
+    if (size > T.directMax || size < 1) return;              // waits for its children (size < 1: not a walk-order subtree)
     F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (int j = 0; j < cnt; j++)
+    for (int j = i; j < i + size; j++)
     {
-        const hrt_instance* in = T.instances + T.tlasInst[first + j];
-        mn = min3(mn, cv3(in->worldBoundsMin)); mx = max3(mx, cv3(in->worldBoundsMax));
+        const int c = node_cnt(nodes, j);
+        const int first = node_link(nodes, j);
+        for (int k = 0; k < c; k++)
+        {
+            const hrt_instance* in = T.instances + T.tlasInst[first + k];
+            mn = min3(mn, cv3(in->worldBoundsMin)); mx = max3(mx, cv3(in->worldBoundsMax));
+        }
     }
     nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
     nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
@@ -140,6 +155,7 @@ __global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
     {
         const int p = T.parent[cur];
         if (p < 0) break;
+        if (cur == i && T.directMax > 1 && subtree_size(T, p) <= T.directMax) break;     // the parent computes its own box
         const int old = __hip_atomic_fetch_add(T.arrive + p, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1 < T.nchild[p]) break;
         const int pskip = node_skip(nodes, p);
@@ -157,33 +173,15 @@ __global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
     }
 }
 
-// ------------------------------------------------------------------ exclusive scans over the node list (one workgroup)
-// nidx[i] = i + leaf slots before node i (position in the TLAS with inlined instance records); lidx[i] = leaves before i
-__global__ void __launch_bounds__(1024) k_scan(TlasDevice T)
+// ------------------------------------------------------------------ exclusive scans over the node list
+// One 64-bit scan carries both sums: low word = leaf slots before node i (i + that = its position in the TLAS with
+// inlined instance records), high word = leaves before node i (its position in the flat leaf list).
+__global__ void __launch_bounds__(kBlock) k_scan_input(TlasDevice T)
 {
-    __shared__ int sA[16], sB[16], carry[2];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { carry[0] = 0; carry[1] = 0; }
-    __syncthreads();
-    for (int base = 0; base < T.nT; base += 1024)
-    {
-        const int i = base + tid;
-        const int a = i < T.nT ? node_cnt(T.tlas, i) : 0, b = a > 0 ? 1 : 0;
-        int ia = a, ib = b;
-        for (int d = 1; d < 64; d <<= 1)
-        {
-            const int ua = __shfl_up(ia, d), ub = __shfl_up(ib, d);
-            if (lane >= d) { ia += ua; ib += ub; }
-        }
-        if (lane == 63) { sA[wv] = ia; sB[wv] = ib; }
-        __syncthreads();
-        int offA = carry[0], offB = carry[1], totA = 0, totB = 0;
-        for (int w = 0; w < 16; w++) { if (w < wv) { offA += sA[w]; offB += sB[w]; } totA += sA[w]; totB += sB[w]; }
-        if (i < T.nT) { T.nidx[i] = i + offA + ia - a; T.lidx[i] = offB + ib - b; }
-        __syncthreads();
-        if (tid == 0) { carry[0] += totA; carry[1] += totB; }
-        __syncthreads();
-    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nT) return;
+    const unsigned long long c = (unsigned long long)node_cnt(T.tlas, i);
+    T.scanIn[i] = c | ((c > 0 ? 1ull : 0ull) << 32);
 }
 
 // ------------------------------------------------------------------ everything that is a function of the packed TLAS
@@ -212,11 +210,11 @@ __global__ void __launch_bounds__(kBlock) k_derive(TlasDevice T)
     T.sa[i] = linked ? 2.f * (dx * dy + dy * dz + dz * dx) : 0.f;
     T.arrive[i] = cnt > 0 ? cnt : 1;          // the refit is over: the counters now carry the SAH weights for k_cost
     // the TLAS with instance records inlined after their leaf (hrt_walker.hpp), as validate_and_pack lays it out
-    const int at = T.nidx[i];
-    const int skX = skip == kEnd ? kEnd : T.nidx[skip];
+    const int at = i + (int)(unsigned)T.scanOut[i];
+    const int skX = skip == kEnd ? kEnd : skip + (int)(unsigned)T.scanOut[skip];
     NodeQ o = q;
     o.hi.w = i2f(skX | (int)((unsigned)cnt << 28));
-    if (cnt == 0) { const int l = link & kEnd; o.lo.w = i2f(l == kEnd ? kEnd : T.nidx[l]); }
+    if (cnt == 0) { const int l = link & kEnd; o.lo.w = i2f(l == kEnd ? kEnd : l + (int)(unsigned)T.scanOut[l]); }
     T.tlasX[at] = o;
     for (int j = 0; j < cnt; j++)
     {
@@ -227,23 +225,40 @@ __global__ void __launch_bounds__(kBlock) k_derive(TlasDevice T)
         rec.hi = make_float4(f.b.x, f.b.y, f.b.z, i2f(next | (int)(15u << 28)));
         T.tlasX[at + 1 + j] = rec;
     }
-    if (cnt > 0 && T.lidx[i] < T.flatMax) T.flat[T.lidx[i]] = q;
+    const int leavesBefore = (int)(T.scanOut[i] >> 32);
+    if (cnt > 0 && leavesBefore < T.flatMax) T.flat[leavesBefore] = q;
 }
 
 // cost[0]: geometric mean over the nodes of area now / area when the tree was last built (1 = as built; a mean that one
 // far-flung instance or one huge instance cannot dominate); cost[1]: the classic estimate sum(area x (leaf ? count : 1)) / area(root).
-// Fixed summation order: reproducible, so HRT_REBUILD_AUTO takes the same decision for the same moves.
-__global__ void __launch_bounds__(1024) k_cost(TlasDevice T)
+// Two stages with a fixed summation order: reproducible, so HRT_REBUILD_AUTO takes the same decision for the same moves.
+__global__ void __launch_bounds__(kBlock) k_cost_partial(TlasDevice T)
 {
-    __shared__ float s[3][1024];
+    __shared__ float s[3][kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
     float lg = 0.f, m = 0.f, sah = 0.f;
-    for (int i = threadIdx.x; i < T.nT; i += 1024)
+    if (i < T.nT)
     {
         const float a = T.sa[i], b = T.saBase[i];
-        sah += a * (float)T.arrive[i];
-        if (a > 0.f && b > 0.f) { lg += __logf(a / b); m += 1.f; }
+        sah = a * (float)T.arrive[i];
+        if (a > 0.f && b > 0.f) { lg = __logf(a / b); m = 1.f; }
     }
     s[0][threadIdx.x] = lg; s[1][threadIdx.x] = m; s[2][threadIdx.x] = sah;
+    __syncthreads();
+    for (int d = kBlock / 2; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d) for (int k = 0; k < 3; k++) s[k][threadIdx.x] += s[k][threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) T.costPartial[3 * blockIdx.x + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ void __launch_bounds__(1024) k_cost(TlasDevice T, int nPartials)
+{
+    __shared__ float s[3][1024];
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nPartials; i += 1024) for (int k = 0; k < 3; k++) acc[k] += T.costPartial[3 * i + k];
+    for (int k = 0; k < 3; k++) s[k][threadIdx.x] = acc[k];
     __syncthreads();
     for (int d = 512; d > 0; d >>= 1)
     {
@@ -265,11 +280,16 @@ HRT_D F3 inst_centroid(const hrt_instance* in)
                0.5f * (in->worldBoundsMin.Z + in->worldBoundsMax.Z));
 }
 
-__global__ void __launch_bounds__(1024) k_centroid_bounds(TlasDevice T)
+// floats as unsigned keys of the same order, so the bounds of all blocks meet in six atomicMin / atomicMax words
+HRT_D unsigned ord_key(float f) { const unsigned u = (unsigned)f2i(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+HRT_D float ord_float(unsigned k) { return i2f((int)((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k)); }
+
+__global__ void __launch_bounds__(kBlock) k_centroid_bounds(TlasDevice T)
 {
-    __shared__ float s[6][16];
+    __shared__ float s[6][kBlock / 64];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
     F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (int i = threadIdx.x; i < T.nI; i += 1024) { const F3 c = inst_centroid(T.instances + i); mn = min3(mn, c); mx = max3(mx, c); }
+    if (i < T.nI) { const F3 c = inst_centroid(T.instances + i); mn = c; mx = c; }
     float v[6] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
     for (int d = 32; d > 0; d >>= 1)
         for (int k = 0; k < 6; k++) { const float o = __shfl_xor(v[k], d); v[k] = k < 3 ? hrt_fmin(v[k], o) : hrt_fmax(v[k], o); }
@@ -280,8 +300,8 @@ __global__ void __launch_bounds__(1024) k_centroid_bounds(TlasDevice T)
     {
         const int k = threadIdx.x;
         float r = s[k][0];
-        for (int w = 1; w < 16; w++) r = k < 3 ? hrt_fmin(r, s[k][w]) : hrt_fmax(r, s[k][w]);
-        T.cbounds[k] = r;
+        for (int w = 1; w < kBlock / 64; w++) r = k < 3 ? hrt_fmin(r, s[k][w]) : hrt_fmax(r, s[k][w]);
+        if (k < 3) atomicMin(T.cboundsKey + k, ord_key(r)); else atomicMax(T.cboundsKey + k, ord_key(r));
     }
 }
 
@@ -307,7 +327,9 @@ __global__ void __launch_bounds__(kBlock) k_morton(TlasDevice T)
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= T.nI) return;
     const F3 c = inst_centroid(T.instances + i);
-    const unsigned x = quant10(c.x, T.cbounds[0], T.cbounds[3]), y = quant10(c.y, T.cbounds[1], T.cbounds[4]), z = quant10(c.z, T.cbounds[2], T.cbounds[5]);
+    float cb[6];
+    for (int k = 0; k < 6; k++) cb[k] = ord_float(T.cboundsKey[k]);
+    const unsigned x = quant10(c.x, cb[0], cb[3]), y = quant10(c.y, cb[1], cb[4]), z = quant10(c.z, cb[2], cb[5]);
     T.keys[i] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
     T.vals[i] = i;
 }
@@ -403,6 +425,13 @@ __global__ void k_single_leaf(TlasDevice T)
 
 } // namespace
 
+size_t tlas_scan_temp_bytes(int n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, n, (hipStream_t) nullptr);
+    return bytes;
+}
+
 size_t tlas_sort_temp_bytes(int n)
 {
     size_t bytes = 0;
@@ -430,10 +459,13 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s)
         k_single_leaf<<<1, 1, 0, s>>>(T);
         return hipGetLastError();
     }
-    k_centroid_bounds<<<1, 1024, 0, s>>>(T);
+    hipError_t e;
+    if ((e = hipMemsetAsync(T.cboundsKey, 0xFF, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(T.cboundsKey + 3, 0, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
+    k_centroid_bounds<<<blocks_for(n), kBlock, 0, s>>>(T);
     k_morton<<<blocks_for(n), kBlock, 0, s>>>(T);
     size_t bytes = T.sortTmpBytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)T.tlasInst, n, 0, 30, s);
+    e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)T.tlasInst, n, 0, 30, s);
     if (e != hipSuccess) return e;
     k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L);
     k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
@@ -448,9 +480,12 @@ hipError_t tlas_finish(const TlasDevice& T, hipStream_t s)
     if ((e = hipMemsetAsync(T.arrive, 0, (size_t)T.nT * sizeof(int), s)) != hipSuccess) return e;
     if (T.nTI > 0) k_leaf_slots<<<blocks_for(T.nTI), kBlock, 0, s>>>(T);
     k_refit<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
-    k_scan<<<1, 1024, 0, s>>>(T);
+    k_scan_input<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
+    size_t bytes = T.scanTmpBytes;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(T.scanTmp, bytes, (const unsigned long long*)T.scanIn, T.scanOut, T.nT, s)) != hipSuccess) return e;
     k_derive<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
-    k_cost<<<1, 1024, 0, s>>>(T);
+    k_cost_partial<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
+    k_cost<<<1, 1024, 0, s>>>(T, blocks_for(T.nT));
     return hipGetLastError();
 }
 

@@ -292,7 +292,7 @@ struct DeviceState {
     void* packed[7] = {};                      // NodeQ tlas, FInst, NodeQ blas, FTri, NodeQ TLAS leaves in walk order (device-private repack)
     DPacked dpacked{};
     TlasDevice tl{};                           // device-side TLAS maintenance (hrt_bvh.hpp); aux arrays below
-    void* tlaux[9] = {};                       // parent, nchild, arrive, nidx, lidx, sa, flags, cost, saBase
+    void* tlaux[10] = {};                      // parent, nchild, arrive, scanIn, scanOut, sa, flags, cost, saBase, scanTmp + costPartial
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     // presentation (TAAU history + display-size colour), device slot 0 only
@@ -436,7 +436,7 @@ void free_scene(DeviceState& d)
 {
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
-    for (int i = 0; i < 9; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
+    for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
 }
@@ -1243,8 +1243,10 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
         }
         {   // maintenance arrays of the device-side TLAS update
-            const size_t ab[9] = {(size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, 16, 16, (size_t)capT * 4};
-            for (int i = 0; i < 9; i++) { HIPCHK(c, hipMalloc(&d.tlaux[i], ab[i])); HIPCHK(c, hipMemsetAsync(d.tlaux[i], 0, ab[i], d.stream)); }
+            const size_t scanTmp = (tlas_scan_temp_bytes((int)capT) + 255) & ~(size_t)255, nPart = (size_t)(capT + 255) / 256;
+            const size_t ab[10] = {(size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 4, (size_t)capT * 8, (size_t)capT * 8, (size_t)capT * 4, 16, 16, (size_t)capT * 4,
+                                   scanTmp + 3 * nPart * 4};
+            for (int i = 0; i < 10; i++) { HIPCHK(c, hipMalloc(&d.tlaux[i], ab[i])); HIPCHK(c, hipMemsetAsync(d.tlaux[i], 0, ab[i], d.stream)); }
             if (!ph.parent.empty())
             {
                 HIPCHK(c, hipMemcpyAsync(d.tlaux[0], ph.parent.data(), std::min(ph.parent.size(), (size_t)capT) * 4, hipMemcpyHostToDevice, d.stream));
@@ -1255,7 +1257,9 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             T.tlasNodes = (hrt_bvh_node*)d.scene[0]; T.tlasInst = (int32_t*)d.scene[1]; T.instances = (hrt_instance*)d.scene[2];
             T.blasNodes = (const hrt_bvh_node*)d.scene[3]; T.spherePrimIdx = (const int32_t*)d.scene[4]; T.spheres = (const hrt_sphere*)d.scene[5];
             T.tlas = (NodeQ*)d.packed[0]; T.finst = (FInst*)d.packed[1]; T.tlasX = (NodeQ*)d.packed[6]; T.flat = (NodeQ*)d.packed[4];
-            T.parent = (int*)d.tlaux[0]; T.nchild = (int*)d.tlaux[1]; T.arrive = (int*)d.tlaux[2]; T.nidx = (int*)d.tlaux[3]; T.lidx = (int*)d.tlaux[4];
+            T.parent = (int*)d.tlaux[0]; T.nchild = (int*)d.tlaux[1]; T.arrive = (int*)d.tlaux[2]; T.scanIn = (unsigned long long*)d.tlaux[3]; T.scanOut = (unsigned long long*)d.tlaux[4];
+            T.scanTmp = d.tlaux[9]; T.scanTmpBytes = scanTmp; T.costPartial = (float*)((char*)d.tlaux[9] + scanTmp);
+            T.directMax = (ph.refit_ok && !getenv("HRT_BUILDER_ORDER")) ? 63 : 1;
             T.sa = (float*)d.tlaux[5]; T.flags = (int*)d.tlaux[6]; T.cost = (float*)d.tlaux[7]; T.saBase = (float*)d.tlaux[8];
             T.nI = (int)s->n_instances; T.nT = (int)s->n_tlasNodes; T.nTI = (int)s->n_tlasInstanceIndices;
             T.capT = (int)capT; T.capTI = (int)capTI; T.flatMax = kFlatMaxLeaves;
@@ -1289,7 +1293,7 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
     T.keys = (unsigned*)take(n * 4); T.keysSorted = (unsigned*)take(n * 4); T.vals = (int*)take(n * 4);
     T.rngA = (int*)take(L * 4); T.rngB = (int*)take(L * 4); T.split = (int*)take(L * 4); T.parInt = (int*)take(L * 4);
     T.parLeaf = (int*)take(L * 4); T.idxInt = (int*)take(L * 4); T.idxLeaf = (int*)take(L * 4);
-    T.cbounds = (float*)take(6 * 4);
+    T.cboundsKey = (unsigned*)take(6 * 4);
     T.sortTmp = take(sortBytes); T.sortTmpBytes = sortBytes;
     return HRT_OK;
 }
@@ -1368,6 +1372,7 @@ int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const 
         {
             if ((rc = ensure_lbvh_scratch(c, d)) != HRT_OK) return rc;
             HIPCHK(c, tlas_rebuild_topology(T, d.stream));
+            T.directMax = 63;                                           // emitted in walk order
             if ((rc = finish_and_read()) != HRT_OK) return rc;
             if ((rc = keep_as_base()) != HRT_OK) return rc;
             h_cost[0] = 1.f;                                            // as built

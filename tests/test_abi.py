@@ -34,9 +34,9 @@ def test_struct_sizes_match_headers():
 #include "hip_raytrace.h"
 #include "hrt_host.h"
 int main(void){
- printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrt_scene_desc), sizeof(hrt_frame_params), sizeof(hrt_stats),
+ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(hrt_scene_desc), sizeof(hrt_frame_params), sizeof(hrt_stats),
    sizeof(hrt_outputs), sizeof(hrt_render_opts), sizeof(hrt_device_views), sizeof(hrt_kernel_counters), sizeof(hrt_instance),
-   sizeof(hrt_sphere), sizeof(hrt_camera));
+   sizeof(hrt_sphere), sizeof(hrt_camera), sizeof(hrt_bvh_update_stats), sizeof(hrt_bvh_node));
  return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
@@ -45,7 +45,7 @@ int main(void){
         subprocess.check_call(["gcc", "-std=c11", "-I", INC, c, "-o", exe])
         got = [int(x) for x in subprocess.check_output([exe]).split()]
     want = [C.sizeof(x) for x in (T.SceneDesc, T.FrameParams, T.Stats, T.Outputs, T.RenderOpts, T.DeviceViews,
-                                  T.KernelCounters, T.InstanceRecord, T.Sphere, T.Camera)]
+                                  T.KernelCounters, T.InstanceRecord, T.Sphere, T.Camera, T.BvhUpdateStats, T.BvhNode)]
     assert got == want
 
 

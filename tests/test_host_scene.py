@@ -120,3 +120,51 @@ def test_default_renderer_camera(hrt_lib):
     engine.camera_translate(c, (1, 0, -4))
     assert (c.origin.X, c.origin.Y, c.origin.Z) == (1.0, 1.0, -1.0)
     assert abs(c.forward.Y + 0.164) < 1e-3 and abs(c.forward.Z + 0.986) < 1e-3
+
+
+MOVES = [("x", 0.0, 1.0, (0.25, -0.5, 3.0)), ("y", 33.0, 1.0, (1.0, 0.0, -2.0)), ("z", -71.5, 0.6, (0.0, 0.0, 0.0)),
+         ("x", 180.0, 2.5, (-4.0, 0.125, 0.75))]
+
+
+@pytest.mark.parametrize("name", ["random_spheres_777", "textured", "blob_40x40"])
+def test_moved_instances_match_oracle(orc, hrt_lib, name):
+    """hrth_scene_set_instance_transform (the host mirror of hrt_scene_update_instances) == the oracle's restatement of
+    what BuildSphereInstance / LoadObjInstance derive from objectToWorld (Scene.cs:395-402,236-252,560-580,616-638);
+    RebuildTLAS afterwards gives the same tree on both sides."""
+    a, b = orc.OrcScene(), engine.Scene()
+    BUILDERS[name](a)
+    BUILDERS[name](b)
+    n = len(a.arrays()["instances"])
+    for k in range(min(n, 9)):
+        m = scenes.rotation_affine(*MOVES[k % len(MOVES)])
+        a.set_instance_transform(n - 1 - k, m)
+        b.set_instance_transform(n - 1 - k, m)
+    _same_arrays(a, b)
+    a.rebuild_tlas(); b.rebuild_tlas()
+    _same_arrays(a, b)
+    with pytest.raises(IndexError):
+        b.set_instance_transform(n, T.identity_affine())
+
+
+def test_moved_instance_known_answers(orc):
+    """Closed forms: a translation keeps the matrix exact; a uniform scale s gives uniformScale = s and worldToObject =
+    I / s (normalised columns times 1 / s, Scene.cs:625-631); a quarter turn about y maps
+    the unit box onto itself with worldToObject equal to the ROTATION, not its transpose (the quirk DESIGN.md 4 records)."""
+    s = orc.OrcScene()
+    sid = s.add_sphere(scenes.sphere((0.0, 0.0, 0.0), 1.0, (1.0, 1.0, 1.0)))
+    s.build_sphere_instance([sid])
+    s.set_instance_transform(0, scenes.rotation_affine("y", 0.0, 1.0, (2.0, -3.0, 0.5)))
+    i = s.arrays()["instances"][0]
+    assert tuple(i["worldBoundsMin"].tolist()) == (1.0, -4.0, -0.5) and tuple(i["worldBoundsMax"].tolist()) == (3.0, -2.0, 1.5)
+    w = i["worldToObject"]
+    assert (w["m00"], w["m11"], w["m22"], w["m03"], w["m13"], w["m23"]) == (1.0, 1.0, 1.0, -2.0, 3.0, -0.5) and i["uniformScale"] == 1.0
+    s.set_instance_transform(0, scenes.rotation_affine("y", 0.0, 4.0, (0.0, 0.0, 0.0)))
+    i = s.arrays()["instances"][0]
+    assert i["uniformScale"] == 4.0 and i["worldToObject"]["m00"] == 0.25 and tuple(i["worldBoundsMax"].tolist()) == (4.0, 4.0, 4.0)
+    q = T.identity_affine()
+    q.m00, q.m02, q.m20, q.m22 = 0.0, 1.0, -1.0, 0.0                   # x -> -z, z -> x
+    s.set_instance_transform(0, q)
+    i = s.arrays()["instances"][0]
+    w = i["worldToObject"]
+    assert (w["m00"], w["m02"], w["m20"], w["m22"]) == (0.0, 1.0, -1.0, 0.0)
+    assert tuple(i["worldBoundsMin"].tolist()) == (-1.0, -1.0, -1.0) and tuple(i["worldBoundsMax"].tolist()) == (1.0, 1.0, 1.0)

@@ -95,3 +95,33 @@ def test_multi_slot_async_frames(multi):
     got, o2 = T.alloc_outputs(256, 144, ["color", "radiance"])
     r.render_params(p, o2)
     H.assert_outputs_equal(ref, got)
+
+
+@pytest.mark.parametrize("policy", [T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD])
+def test_moved_instances_on_every_slot(orc, multi, policy):
+    """hrt_scene_update_instances updates the tree of every device slot the same way (same kernels, deterministic):
+    the slots' downloads are equal and the tiled frame equals the oracle on the downloaded arrays."""
+    from tests import test_bvh_update_gpu as B
+    r = multi[2]
+    builder, cfg, w, h, spp = B.SCENES["sphere_instances"]
+    s = engine.Scene(); builder(s); r.commit(s); r.reset_history()
+    so = orc.OrcScene(); builder(so)
+    ids, xfs = B._moves(len(so.arrays()["instances"]), "rigid")
+    r.update_instances(ids, xfs, policy)
+    for i, m in zip(ids, xfs):
+        so.set_instance_transform(i, m)
+    per_slot = []
+    for slot in range(2):
+        nodes, idx, inst, cnt = r.download_tlas(slot)
+        per_slot.append((B._as_np(nodes, cnt[0], T.BvhNode), np.frombuffer(idx, dtype=np.int32, count=cnt[1]).copy(), B._as_np(inst, cnt[2], T.InstanceRecord)))
+    for a, b in zip(per_slot[0], per_slot[1]):
+        assert a.tobytes() == b.tobytes()
+    nodes, idx, inst = per_slot[0]
+    assert inst.tobytes() == so.arrays()["instances"].tobytes()
+    ref, ost = B._oracle_render(orc, B._desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+    p = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+    got, o = T.alloc_outputs(w, h)
+    st = r.render_params(p, o, flags=T.FLAG_COUNTERS)
+    H.assert_outputs_equal(ref, got)
+    for i in range(2):
+        assert st.k[i].as_dict() == ost.k[i].as_dict()
