@@ -272,3 +272,63 @@ def test_update_errors(renderer):
     with pytest.raises(engine.HrtError, match="too small"):
         renderer._check(engine.lib().hrt_scene_download_tlas(renderer._ctx, 0, nodes, 1, None, 0, None, 0, cnt))
     assert cnt[0] > 1
+
+
+def _refit_numpy_fast(nodes, idx, inst):
+    """_refit_numpy for big trees: walk-order numbering (children after parents), so one reverse sweep is bottom-up."""
+    lo = np.stack([nodes["boundsMin"][f] for f in "XYZ"], axis=1).copy()
+    hi = np.stack([nodes["boundsMax"][f] for f in "XYZ"], axis=1).copy()
+    ilo = np.stack([inst["worldBoundsMin"][f] for f in "XYZ"], axis=1)
+    ihi = np.stack([inst["worldBoundsMax"][f] for f in "XYZ"], axis=1)
+    for i in range(len(nodes) - 1, -1, -1):
+        n = nodes[i]
+        if n["count"] > 0:
+            ids = idx[n["first"]:n["first"] + n["count"]]
+            lo[i], hi[i] = ilo[ids].min(axis=0), ihi[ids].max(axis=0)
+        else:
+            l, r = int(n["left"]), int(n["right"])
+            assert l == i + 1 and r > l
+            lo[i], hi[i] = np.minimum(lo[l], lo[r]), np.maximum(hi[l], hi[r])
+    out = nodes.copy()
+    for k, f in enumerate("XYZ"):
+        out["boundsMin"][f] = lo[:, k]
+        out["boundsMax"][f] = hi[:, k]
+    return out
+
+
+def test_big_tree_refit_and_rebuild(orc, renderer):
+    """4001 instances: subtrees of more than 63 nodes take the arrival-counter climb of the refit kernel, the LBVH sorts
+    real Morton keys (with duplicates: the jitter is quantised), the scan and cost kernels span many workgroups."""
+    n = 4000
+    s = engine.Scene(); scenes.build_random_spheres(s, n, extent=12.0); renderer.commit(s)
+    so = orc.OrcScene(); scenes.build_random_spheres(so, n, extent=12.0)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    rng = np.random.default_rng(11)
+    xf = np.zeros((n, 12), np.float32); xf[:, 0] = xf[:, 5] = xf[:, 10] = 1.0
+    xf[:, [3, 7, 11]] = np.round(rng.uniform(-2.0, 2.0, (n, 3)) * 4.0).astype(np.float32) / 4.0
+    for k in range(n):
+        m = T.identity_affine(); m.m03, m.m13, m.m23 = float(xf[k, 3]), float(xf[k, 7]), float(xf[k, 11])
+        so.set_instance_transform(int(ids[k]), m)
+    oa = so.arrays()
+    # refit: the uploaded topology (walk order) with recomputed boxes
+    st = renderer.update_instances(ids, xf, T.REBUILD_FORCE_REFIT)
+    nodes, idx, inst = _download(renderer)
+    assert st.action == T.REBUILD_FORCE_REFIT and len(nodes) == len(oa["tlasNodes"]) > 63 * 32
+    assert inst.tobytes() == oa["instances"].tobytes()
+    assert nodes.tobytes() == _refit_numpy_fast(nodes, idx, inst).tobytes()
+    want = _walk(_refit_numpy(oa["tlasNodes"], oa["tlasInstanceIndices"], oa["instances"]), oa["tlasInstanceIndices"])
+    assert _walk(nodes, idx) == want
+    # rebuild
+    st = renderer.update_instances([], [], T.REBUILD_FORCE_REBUILD)
+    nodes, idx, inst = _download(renderer)
+    assert sorted(idx.tolist()) == list(range(n + 1)) and len(nodes) == 2 * ((n + 2) // 2) - 1 == st.tlas_nodes
+    assert len(_walk(nodes, idx)) == len(nodes)
+    assert nodes.tobytes() == _refit_numpy_fast(nodes, idx, inst).tobytes()
+    cfg, w, h, spp = scenes.CONFIGS[3], 160, 96, 1
+    ref, ost = _oracle_render(orc, _desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+    got, gst = _gpu_render(renderer, cfg, w, h, spp, T.FLAG_COUNTERS)
+    H.assert_outputs_equal(ref, got)
+    assert gst.k[1].as_dict() == ost.k[1].as_dict()
+    so.rebuild_tlas()                                       # translations only: the host's tree shows the same picture
+    host, _ = _oracle_render(orc, so.desc(), cfg, w, h, spp)
+    H.assert_outputs_equal(host, ref)
