@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(kBlock) k_set_transforms(TlasDevice T, const i
     if (k >= n) return;
     const int ii = ids[k];
     hrt_instance* in = T.instances + ii;
-    const hrt_affine3x4 m = xf[k];
+    const hrt_affine3x4 m = xf ? xf[k] : in->objectToWorld;
     F3 bmin = mk3(0.f, 0.f, 0.f), bmax = bmin;
     if (in->blasNodeCount > 0)
     {
@@ -423,7 +423,107 @@ __global__ void k_single_leaf(TlasDevice T)
     for (int i = 0; i < T.nI; i++) T.tlasInst[i] = i;
 }
 
+// ------------------------------------------------------------------ triangle-mesh BLASes after a vertex update
+__global__ void __launch_bounds__(kBlock) k_copy_positions(hrt_float3* dst, const hrt_float3* src, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// one thread per leaf slot: the three vertices of the slot's triangle (index, material and flags in the .w lanes stay)
+__global__ void __launch_bounds__(kBlock) k_tri_records(BlasDevice B)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= B.nSlots) return;
+    FTri* r = B.ftri + j;
+    const hrt_mesh_tri t = B.meshTris[f2i(r->v0.w)];
+    const hrt_float3 a = B.positions[t.i0], b = B.positions[t.i1], c = B.positions[t.i2];
+    r->v0.x = a.X; r->v0.y = a.Y; r->v0.z = a.Z;
+    r->v1.x = b.X; r->v1.y = b.Y; r->v1.z = b.Z;
+    r->v2.x = c.X; r->v2.y = c.Y; r->v2.z = c.Z;
+}
+
+// Same scheme as k_refit: subtrees of up to directMax nodes straight from their triangles (BoundsOfTriangle over the
+// node's items, Scene.cs:423-429,597-605), arrival counters above.
+__global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.nB || B.parent[i] == -2) return;
+    NodeQ* nodes = B.blas;
+    const int size = B.subend[i] - i;
+    if (size > B.directMax || size < 1) return;
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int j = i; j < i + size; j++)
+    {
+        const int c = node_cnt(nodes, j);
+        const int first = node_link(nodes, j);
+        for (int k = 0; k < c; k++)
+        {
+            const FTri t = B.ftri[first + k];
+            const F3 a = mk3(t.v0.x, t.v0.y, t.v0.z), b = mk3(t.v1.x, t.v1.y, t.v1.z), cc = mk3(t.v2.x, t.v2.y, t.v2.z);
+            mn = min3(mn, min3(a, min3(b, cc))); mx = max3(mx, max3(a, max3(b, cc)));
+        }
+    }
+    nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
+    nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
+    int cur = i;
+    for (;;)
+    {
+        const int p = B.parent[cur];
+        if (p < 0) break;
+        if (cur == i && B.subend[p] - p <= B.directMax) break;
+        const int old = __hip_atomic_fetch_add(B.arrive + p, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 < B.nchild[p]) break;
+        const int pskip = node_skip(nodes, p);
+        mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX); mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+        int c = node_link(nodes, p) & kEnd;
+        for (int guard = 0; c != kEnd && c != pskip && guard < 64; guard++)
+        {
+            const float4 lo = nodes[c].lo, hi = nodes[c].hi;
+            mn = min3(mn, mk3(lo.x, lo.y, lo.z)); mx = max3(mx, mk3(hi.x, hi.y, hi.z));
+            c = f2i(hi.w) & kEnd;
+        }
+        nodes[p].lo.x = mn.x; nodes[p].lo.y = mn.y; nodes[p].lo.z = mn.z;
+        nodes[p].hi.x = mx.x; nodes[p].hi.y = mx.y; nodes[p].hi.z = mx.z;
+        cur = p;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.nB || B.parent[i] == -2) return;
+    const NodeQ q = B.blas[i];
+    hrt_bvh_node* r = B.blasNodes + B.orig[i];
+    r->boundsMin.X = q.lo.x; r->boundsMin.Y = q.lo.y; r->boundsMin.Z = q.lo.z;
+    r->boundsMax.X = q.hi.x; r->boundsMax.Y = q.hi.y; r->boundsMax.Z = q.hi.z;
+}
+
 } // namespace
+
+hipError_t blas_set_positions(const BlasDevice& B, int first, int n, const hrt_float3* posDev, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    k_copy_positions<<<blocks_for(n), kBlock, 0, s>>>(B.positions + first, posDev, n);
+    return hipGetLastError();
+}
+
+hipError_t blas_refit(const BlasDevice& B, hipStream_t s)
+{
+    hipError_t e;
+    if ((e = hipMemsetAsync(B.arrive, 0, (size_t)B.nB * sizeof(int), s)) != hipSuccess) return e;
+    if (B.nSlots > 0) k_tri_records<<<blocks_for(B.nSlots), kBlock, 0, s>>>(B);
+    k_blas_refit<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
+    k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
+    return hipGetLastError();
+}
+
+hipError_t tlas_rebound_instances(const TlasDevice& T, const int32_t* idsDev, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    k_set_transforms<<<blocks_for(n), kBlock, 0, s>>>(T, idsDev, nullptr, n);
+    return hipGetLastError();
+}
 
 size_t tlas_scan_temp_bytes(int n)
 {

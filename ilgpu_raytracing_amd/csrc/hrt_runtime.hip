@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <string>
 #include <vector>
 #include "hrt_device.hpp"
@@ -295,6 +296,9 @@ struct DeviceState {
     void* tlaux[10] = {};                      // parent, nchild, arrive, scanIn, scanOut, sa, flags, cost, saBase, scanTmp + costPartial
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
+    BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
+    void* blaux[6] = {};                       // parent, nchild, subend, orig, arrive, ids of the TriMesh instances
+    int n_mesh_inst = 0;
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
@@ -331,6 +335,9 @@ struct hrt_ctx {
     int64_t n_inst = 0, n_tlas = 0, n_slots = 0, n_blas = 0;
     int tlas_leaves = 0;                       // reachable leaves of the TLAS in use
     bool tlas_on_device = false;               // the TLAS in use was refitted / rebuilt on the device (walk-order numbering)
+    bool blas_refit_ok = false;                // hrt_scene_update_positions can refit every triangle-mesh BLAS
+    int64_t n_positions = 0;
+    int64_t scene_count[15] = {};
     int width = 0, height = 0;
 };
 
@@ -439,6 +446,8 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
+    for (int i = 0; i < 6; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
+    d.bl = BlasDevice{}; d.n_mesh_inst = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -458,6 +467,10 @@ struct PackedHost {
     int n_tlasX = 0;          // records in tlasX (0: not built)
     int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
     std::vector<int32_t> parent, nchild;     // TLAS, packed numbering: parent of a node (-1: none), children of an inner node
+    std::vector<int32_t> bparent, bnchild, bsubend, borig;   // BLAS nodes of triangle meshes, packed numbering: parent (-1 root, -2 not maintained),
+                                                             // children, end of the subtree's index range, index in the uploaded numbering
+    std::vector<int32_t> meshInst;                           // ids of the TriMesh instances whose BLAS is maintained
+    bool blas_refit_ok = true;                               // every TriMesh BLAS can be refitted on the device
     bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
     int reach_leaves = 0;     // reachable TLAS leaves
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
@@ -625,11 +638,15 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         ranges.erase(std::unique(ranges.begin(), ranges.end()), ranges.end());
         bool disjoint = true;
         for (size_t i = 1; i < ranges.size(); i++) if (ranges[i].first < ranges[i - 1].second) disjoint = false;
+        const size_t nBq = out.blas.size();
+        out.bparent.assign(nBq, -2); out.bnchild.assign(nBq, 0); out.bsubend.assign(nBq, 0); out.borig.assign(nBq, 0);
+        for (size_t j = 0; j < nBq; j++) out.borig[j] = (int32_t)j;
         if (!disjoint)
         {
             perm.resize((size_t)nB);
             for (size_t j = 0; j < perm.size(); j++) perm[j] = (int32_t)j;
             pack_range(s->blasNodes, 0, nB, perm, out.blas);
+            out.blas_refit_ok = false;
         }
         else
         {
@@ -637,12 +654,38 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             for (const auto& r : ranges)
             {
                 for (; at < r.first; at++) { perm.assign(1, 0); pack_range(s->blasNodes, at, at + 1, perm, out.blas); }   // owned by no instance: never walked
-                walk_order(s->blasNodes, r.first, r.second, r.first, perm);
+                const int32_t reach = walk_order(s->blasNodes, r.first, r.second, r.first, perm);
                 pack_range(s->blasNodes, r.first, r.second, perm, out.blas);
                 at = r.second;
+                // maintenance arrays for the BLAS of a triangle mesh (device refit after a vertex update, hrt_bvh.hpp)
+                bool mesh = false, other = false;
+                for (int64_t i = 0; i < nI; i++)
+                    if (s->instances[i].blasNodeCount > 0 && s->instances[i].blasRoot == r.first && (int64_t)s->instances[i].blasRoot + s->instances[i].blasNodeCount == r.second)
+                        (s->instances[i].type == HRT_BLAS_TRIMESH ? mesh : other) = true;
+                if (!mesh) continue;
+                if (other || reach != (int32_t)(r.second - r.first)) { out.blas_refit_ok = false; continue; }   // shared with a sphere set, unreachable nodes or builder numbering
+                auto cntq = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.blas[(size_t)i].hi.w) >> 28); };
+                auto skipq = [&](int64_t i) { return __builtin_bit_cast(int, out.blas[(size_t)i].hi.w) & kEnd; };
+                for (int64_t k = r.first; k < r.second; k++) out.borig[(size_t)(r.first + perm[(size_t)(k - r.first)])] = (int32_t)k;
+                out.bparent[(size_t)r.first] = -1;
+                for (int64_t i = r.first; i < r.second; i++)
+                {
+                    const int sk = skipq(i);
+                    out.bsubend[(size_t)i] = (int32_t)(sk == kEnd ? r.second : sk);
+                    if (cntq(i) > 0) continue;
+                    int c = __builtin_bit_cast(int, out.blas[(size_t)i].lo.w) & kEnd;
+                    int steps = 0;
+                    while (c != kEnd && c != sk)
+                    {
+                        if (c <= i || c >= r.second || out.bparent[(size_t)c] != -2 || ++steps > 64) { out.blas_refit_ok = false; break; }
+                        out.bparent[(size_t)c] = (int32_t)i; out.bnchild[(size_t)i]++;
+                        c = skipq(c);
+                    }
+                }
             }
             for (; at < nB; at++) { perm.assign(1, 0); pack_range(s->blasNodes, at, at + 1, perm, out.blas); }
         }
+        for (int64_t i = 0; i < nI; i++) if (s->instances[i].type == HRT_BLAS_TRIMESH && s->instances[i].blasNodeCount > 0) out.meshInst.push_back((int32_t)i);
     }
     if (nT == 0)
     {   // reference semantics of the zeroed 1-element TLAS: node 0 has count 0, left 0 -> loops forever on a hit;
@@ -1202,6 +1245,9 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->n_inst = s->n_instances; c->n_tlas = s->n_tlasNodes; c->n_slots = s->n_tlasInstanceIndices; c->n_blas = s->n_blasNodes;
     c->tlas_leaves = ph.reach_leaves;
     c->tlas_on_device = false;
+    c->blas_refit_ok = ph.blas_refit_ok && ph.ok;
+    c->n_positions = s->n_meshPositions;
+    for (int i = 0; i < 15; i++) c->scene_count[i] = cnt[i];
     // room for a TLAS rebuilt on the device over all instances (leaves of two: hrt_bvh.hpp)
     const int64_t capT = std::max<int64_t>(std::max<int64_t>(s->n_tlasNodes, 2 * ((s->n_instances + 1) / 2) - 1), 1);
     const int64_t capTI = std::max<int64_t>(std::max<int64_t>(s->n_tlasInstanceIndices, s->n_instances), 1);
@@ -1262,6 +1308,24 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             T.directMax = (ph.refit_ok && !getenv("HRT_BUILDER_ORDER")) ? 63 : 1;
             T.sa = (float*)d.tlaux[5]; T.flags = (int*)d.tlaux[6]; T.cost = (float*)d.tlaux[7]; T.saBase = (float*)d.tlaux[8];
             T.nI = (int)s->n_instances; T.nT = (int)s->n_tlasNodes; T.nTI = (int)s->n_tlasInstanceIndices;
+            if (!ph.meshInst.empty() && ph.blas_refit_ok)
+            {
+                const size_t nBq = ph.blas.size();
+                const void* bsrc[6] = {ph.bparent.data(), ph.bnchild.data(), ph.bsubend.data(), ph.borig.data(), nullptr, ph.meshInst.data()};
+                const size_t bb[6] = {nBq * 4, nBq * 4, nBq * 4, nBq * 4, nBq * 4, ph.meshInst.size() * 4};
+                for (int i = 0; i < 6; i++)
+                {
+                    HIPCHK(c, hipMalloc(&d.blaux[i], bb[i]));
+                    if (bsrc[i]) HIPCHK(c, hipMemcpyAsync(d.blaux[i], bsrc[i], bb[i], hipMemcpyHostToDevice, d.stream));
+                    else HIPCHK(c, hipMemsetAsync(d.blaux[i], 0, bb[i], d.stream));
+                }
+                BlasDevice& B = d.bl;
+                B.blasNodes = (hrt_bvh_node*)d.scene[3]; B.triPrimIdx = (const int32_t*)d.scene[6]; B.meshTris = (const hrt_mesh_tri*)d.scene[8];
+                B.positions = (hrt_float3*)d.scene[7]; B.blas = (NodeQ*)d.packed[2]; B.ftri = (FTri*)d.packed[3];
+                B.parent = (int*)d.blaux[0]; B.nchild = (int*)d.blaux[1]; B.subend = (int*)d.blaux[2]; B.orig = (int*)d.blaux[3]; B.arrive = (int*)d.blaux[4];
+                B.nB = (int)s->n_blasNodes; B.nSlots = (int)s->n_triPrimIdx; B.directMax = 63;
+                d.n_mesh_inst = (int)ph.meshInst.size();
+            }
             T.capT = (int)capT; T.capTI = (int)capTI; T.flatMax = kFlatMaxLeaves;
         }
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
@@ -1300,27 +1364,21 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 
 } // namespace
 
-int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const hrt_affine3x4* xf, int32_t policy, hrt_bvh_update_stats* st)
+namespace {
+
+// Shared tail of the scene updates: `mutate` enqueues what changes the instance records on one device (staging buffers it
+// allocates go into the vector and are freed here), then the TLAS is refitted / rebuilt per `policy` and the walkers' view of
+// the tree is refreshed.
+int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<int(DeviceState&, std::vector<void*>&)>& mutate, hrt_bvh_update_stats* st)
 {
-    if (!c) return HRT_ERR_INVALID_ARG;
-    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: no scene uploaded");
-    if (n < 0 || (n > 0 && (!ids || !xf))) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: n instances need ids and transforms");
     if (policy != HRT_REBUILD_AUTO && policy != HRT_REBUILD_FORCE_REFIT && policy != HRT_REBUILD_FORCE_REBUILD)
-        return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: unknown policy");
-    if (!c->packed_ok) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: the scene exceeds the limits of the packed layout");
-    if (c->n_inst <= 0) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: the scene has no instances");
-    {
-        std::vector<uint8_t> seen((size_t)c->n_inst, 0);
-        for (int i = 0; i < n; i++)
-        {
-            if (ids[i] < 0 || ids[i] >= c->n_inst) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id out of range");
-            if (seen[(size_t)ids[i]]++) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id listed twice");
-        }
-    }
+        return fail(c, HRT_ERR_INVALID_ARG, std::string(who) + ": unknown policy");
+    if (!c->packed_ok) return fail(c, HRT_ERR_INVALID_STATE, std::string(who) + ": the scene exceeds the limits of the packed layout");
+    if (c->n_inst <= 0) return fail(c, HRT_ERR_INVALID_STATE, std::string(who) + ": the scene has no instances");
     if (policy != HRT_REBUILD_FORCE_REBUILD && !c->refit_ok && !c->tlas_on_device)
     {
         if (policy == HRT_REBUILD_FORCE_REFIT)
-            return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: this TLAS cannot be refitted (a node has several parents or more than 64 children); use HRT_REBUILD_FORCE_REBUILD");
+            return fail(c, HRT_ERR_INVALID_STATE, std::string(who) + ": this TLAS cannot be refitted (a node has several parents or more than 64 children); use HRT_REBUILD_FORCE_REBUILD");
         policy = HRT_REBUILD_FORCE_REBUILD;
     }
     int rc = hrt_synchronize(c, nullptr);
@@ -1351,15 +1409,8 @@ int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const 
             HIPCHK(c, tlas_finish(T, d.stream));
             if ((rc = keep_as_base()) != HRT_OK) return rc;
         }
-        void* staged = nullptr;
-        if (n > 0)
-        {
-            const size_t idb = ((size_t)n * 4 + 63) & ~(size_t)63;
-            HIPCHK(c, hipMalloc(&staged, idb + (size_t)n * sizeof(hrt_affine3x4)));
-            HIPCHK(c, hipMemcpyAsync(staged, ids, (size_t)n * 4, hipMemcpyHostToDevice, d.stream));
-            HIPCHK(c, hipMemcpyAsync((char*)staged + idb, xf, (size_t)n * sizeof(hrt_affine3x4), hipMemcpyHostToDevice, d.stream));
-            HIPCHK(c, tlas_set_transforms(T, (const int32_t*)staged, (const hrt_affine3x4*)((char*)staged + idb), n, d.stream));
-        }
+        std::vector<void*> staged;
+        if ((rc = mutate(d, staged)) != HRT_OK) return rc;
         int action = policy == HRT_REBUILD_FORCE_REBUILD ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT;
         float growthRefit = 0.f;
         if (action == HRT_REBUILD_FORCE_REFIT)
@@ -1379,7 +1430,7 @@ int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const 
         }
         HIPCHK(c, hipEventRecord(e1, d.stream));
         HIPCHK(c, hipEventSynchronize(e1));
-        if (staged) HIPCHK(c, hipFree(staged));
+        for (void* p : staged) HIPCHK(c, hipFree(p));
         // the walkers' view of the tree
         const bool general = h_flags[0] != 0;
         d.dpacked.nTlas = T.nT;
@@ -1405,6 +1456,68 @@ int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const 
         }
     }
     if (st) *st = out;
+    return HRT_OK;
+}
+
+} // namespace
+
+int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const hrt_affine3x4* xf, int32_t policy, hrt_bvh_update_stats* st)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: no scene uploaded");
+    if (n < 0 || (n > 0 && (!ids || !xf))) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: n instances need ids and transforms");
+    {
+        std::vector<uint8_t> seen((size_t)std::max<int64_t>(c->n_inst, 0), 0);
+        for (int i = 0; i < n; i++)
+        {
+            if (ids[i] < 0 || ids[i] >= c->n_inst) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id out of range");
+            if (seen[(size_t)ids[i]]++) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: instance id listed twice");
+        }
+    }
+    return apply_update(c, policy, "hrt_scene_update_instances", [&](DeviceState& d, std::vector<void*>& staged) -> int {
+        if (n <= 0) return HRT_OK;
+        const size_t idb = ((size_t)n * 4 + 63) & ~(size_t)63;
+        void* buf = nullptr;
+        HIPCHK(c, hipMalloc(&buf, idb + (size_t)n * sizeof(hrt_affine3x4)));
+        staged.push_back(buf);
+        HIPCHK(c, hipMemcpyAsync(buf, ids, (size_t)n * 4, hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, hipMemcpyAsync((char*)buf + idb, xf, (size_t)n * sizeof(hrt_affine3x4), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, tlas_set_transforms(d.tl, (const int32_t*)buf, (const hrt_affine3x4*)((char*)buf + idb), n, d.stream));
+        return HRT_OK;
+    }, st);
+}
+
+int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_float3* positions, int32_t policy, hrt_bvh_update_stats* st)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: no scene uploaded");
+    if (first < 0 || n < 0 || first + n > c->n_positions || (n > 0 && !positions))
+        return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_positions: vertex range outside meshPositions");
+    if (!c->blas_refit_ok)
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: a triangle-mesh BLAS of this scene cannot be refitted (shared or overlapping node ranges, unreachable nodes)");
+    return apply_update(c, policy, "hrt_scene_update_positions", [&](DeviceState& d, std::vector<void*>&) -> int {
+        if (n > 0) HIPCHK(c, hipMemcpyAsync((hrt_float3*)d.scene[7] + first, positions, (size_t)n * sizeof(hrt_float3), hipMemcpyHostToDevice, d.stream));
+        if (d.bl.nSlots > 0) HIPCHK(c, blas_refit(d.bl, d.stream));
+        HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[5], d.n_mesh_inst, d.stream));
+        return HRT_OK;
+    }, st);
+}
+
+int hrt_scene_download_array(hrt_ctx* c, int dev, int array, void* dst, int64_t cap, int64_t* count)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_download_array: no scene uploaded");
+    if (dev < 0 || dev >= (int)c->dev.size() || array < 0 || array >= 15) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_array: device slot or array index out of range");
+    int rc = hrt_synchronize(c, nullptr);
+    if (rc != HRT_OK) return rc;
+    const int64_t have = array == 0 ? c->n_tlas : (array == 1 ? c->n_slots : c->scene_count[array]);
+    if (count) *count = have;
+    if (!dst) return HRT_OK;
+    if (cap < have) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_array: destination too small");
+    DeviceState& d = c->dev[(size_t)dev];
+    HIPCHK(c, hipSetDevice(d.device_id));
+    if (have > 0) HIPCHK(c, hipMemcpyAsync(dst, d.scene[array], (size_t)have * kSceneElem[array], hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(c, hipStreamSynchronize(d.stream));
     return HRT_OK;
 }
 

@@ -51,6 +51,8 @@ def lib():
         L.hrt_last_error.restype = C.c_char_p
         L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrt_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+        L.hrt_scene_update_positions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+        L.hrt_scene_download_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.hrt_scene_download_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                               C.POINTER(C.c_int64)]
         L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
@@ -371,6 +373,25 @@ class RTRenderer:
         self._check(lib().hrt_scene_update_instances(self._ctx, ids.ctypes.data if ids.size else None, ids.size,
                                                      xf.ctypes.data if ids.size else None, policy, C.byref(st)))
         return st
+
+    def update_positions(self, first_vertex, positions, policy=T.REBUILD_AUTO):
+        """Deforming meshes: meshPositions[first_vertex : first_vertex + n] := positions ((n, 3) float32); every triangle-mesh
+        BLAS is refitted on the device, then the TLAS per `policy` (hrt_scene_update_positions).  Returns BvhUpdateStats."""
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        st = T.BvhUpdateStats()
+        self._check(lib().hrt_scene_update_positions(self._ctx, int(first_vertex), pos.shape[0], pos.ctypes.data if pos.size else None,
+                                                     policy, C.byref(st)))
+        return st
+
+    def download_array(self, name, slot=0):
+        """One of the 15 scene arrays as it is on the device now (numpy structured array / int32)."""
+        names = [n for n, _ in T.SCENE_ARRAYS]
+        k = names.index(name)
+        cnt = C.c_int64()
+        self._check(lib().hrt_scene_download_array(self._ctx, slot, k, None, 0, C.byref(cnt)))
+        out = np.zeros(max(1, cnt.value), dtype=T.np_dtype(T.SCENE_ARRAYS[k][1]))
+        self._check(lib().hrt_scene_download_array(self._ctx, slot, k, out.ctypes.data, len(out), C.byref(cnt)))
+        return out[:cnt.value]
 
     def download_tlas(self, slot=0):
         """(tlasNodes, tlasInstanceIndices, instances) of the TLAS in use, as ctypes arrays in the reference's layout."""

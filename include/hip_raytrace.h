@@ -199,6 +199,20 @@ typedef struct hrt_bvh_update_stats {
 int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32_t n, const hrt_affine3x4* objectToWorld,
                                 int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
 
+/* ---- deforming meshes: meshPositions[first_vertex, first_vertex + n) := positions (n may be 0).
+ * The reference has no counterpart (its Commit rebuilds every BLAS on the host, Scene.cs:405-467, and re-uploads): here
+ * every triangle-mesh BLAS keeps its topology and gets its triangle records and boxes recomputed bottom-up on the device
+ * (BoundsOfTriangle over the items of each node, Scene.cs:423-429,597-605), the world bounds of the mesh instances are
+ * re-derived from the new root boxes (TransformAABB, Scene.cs:560-580), and the TLAS is refitted / rebuilt per `policy`
+ * as in hrt_scene_update_instances.  Sphere BLASes are untouched.  Blocking; every device of the context is updated. */
+int  hrt_scene_update_positions(hrt_ctx* ctx, int64_t first_vertex, int64_t n, const hrt_float3* positions,
+                                int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
+
+/* Copies scene array `array` (0..14, in the order of hrt_scene_desc / SceneDeviceViews.cs:13-27) as it is now on device
+ * slot `dev` back to the host: what TracerRef walks after updates.  *count (may be NULL) receives the element count;
+ * dst may be NULL to query it; cap = capacity of dst in elements. */
+int  hrt_scene_download_array(hrt_ctx* ctx, int dev, int array, void* dst, int64_t cap, int64_t* count);
+
 /* Copies the TLAS in use on device slot `dev`, in the reference's layout, and the instance records to the host
  * (any pointer may be NULL).  counts[3] (may be NULL) receives the element counts {tlasNodes, tlasInstanceIndices,
  * instances}; an array is copied only if its capacity (in elements) is large enough, else HRT_ERR_INVALID_ARG. */

@@ -332,3 +332,102 @@ def test_big_tree_refit_and_rebuild(orc, renderer):
     so.rebuild_tlas()                                       # translations only: the host's tree shows the same picture
     host, _ = _oracle_render(orc, so.desc(), cfg, w, h, spp)
     H.assert_outputs_equal(host, ref)
+
+
+# ------------------------------------------------------------------ deforming meshes: hrt_scene_update_positions
+def _f3(v):
+    return np.array(list(v.tolist()), np.float32)
+
+
+def _refit_blas_numpy(arrs):
+    """Boxes of every triangle-mesh BLAS recomputed for arrs['meshPositions'] (topology kept), then the world bounds of
+    those instances (TransformAABB of the root box, Scene.cs:560-580, float32 in the reference's expression order)."""
+    nodes, inst = arrs["blasNodes"].copy(), arrs["instances"].copy()
+    pos = np.stack([arrs["meshPositions"][f] for f in "XYZ"], axis=1)
+    tris = np.stack([arrs["meshTris"][f] for f in ("i0", "i1", "i2")], axis=1)
+    prim = arrs["triPrimIdx"]
+
+    def rec(i):
+        n = nodes[i]
+        if n["count"] > 0:
+            v = pos[tris[prim[n["first"]:n["first"] + n["count"]]].reshape(-1)]
+            lo, hi = v.min(axis=0), v.max(axis=0)
+        else:
+            a, b = rec(int(n["left"])), rec(int(n["right"]))
+            lo, hi = np.minimum(a[0], b[0]), np.maximum(a[1], b[1])
+        for k, f in enumerate("XYZ"):
+            nodes[i]["boundsMin"][f] = lo[k]
+            nodes[i]["boundsMax"][f] = hi[k]
+        return lo, hi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    for ii in range(len(inst)):
+        if inst[ii]["type"] != 2 or inst[ii]["blasNodeCount"] <= 0:
+            continue
+        lo, hi = rec(int(inst[ii]["blasRoot"]))
+        m = inst[ii]["objectToWorld"]
+        rows = [[np.float32(m["m%d%d" % (r, c)]) for c in range(4)] for r in range(3)]
+        corners = [(lo[0], lo[1], lo[2]), (hi[0], lo[1], lo[2]), (lo[0], hi[1], lo[2]), (lo[0], lo[1], hi[2]),
+                   (hi[0], hi[1], lo[2]), (lo[0], hi[1], hi[2]), (hi[0], lo[1], hi[2]), (hi[0], hi[1], hi[2])]
+        w = np.array([[((r[0] * c[0] + r[1] * c[1]) + r[2] * c[2]) + r[3] for r in rows] for c in corners], np.float32)
+        for k, f in enumerate("XYZ"):
+            inst[ii]["worldBoundsMin"][f] = w[:, k].min()
+            inst[ii]["worldBoundsMax"][f] = w[:, k].max()
+    return nodes, inst
+
+
+MESH_SCENES = {
+    "blob_24x24": (lambda b: scenes.build_config4(b, 24, 24), scenes.CONFIGS[4], 128, 72, 2),
+    "textured_alpha_meshes": (scenes.build_textured_test_scene, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0)), 128, 80, 2),
+    "rotated_mesh_and_sets": (scenes.build_rotated_instances_scene, CFG_ROT, 128, 80, 2),
+}
+
+
+@pytest.mark.parametrize("policy", [T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD])
+@pytest.mark.parametrize("name", list(MESH_SCENES))
+def test_deformed_meshes_are_refitted_on_the_device(orc, renderer, name, policy):
+    builder, cfg, w, h, spp = MESH_SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    arrs = s.arrays()
+    pos = np.stack([arrs["meshPositions"][f] for f in "XYZ"], axis=1)
+    n = len(pos)
+    first, cnt = n // 5, n - n // 5 - 3                                  # a sub-range: the rest keeps its place
+    wob = (1.0 + 0.12 * np.sin(7.0 * pos[:, [1, 2, 0]] + 0.3)).astype(np.float32)
+    new = pos.copy()
+    new[first:first + cnt] = (pos * wob)[first:first + cnt]
+    st = renderer.update_positions(first, new[first:first + cnt], policy)
+    assert st.action == policy
+    for k, f in enumerate("XYZ"):
+        arrs["meshPositions"][f] = new[:, k]
+    want_blas, want_inst = _refit_blas_numpy(arrs)
+    assert renderer.download_array("meshPositions").tobytes() == arrs["meshPositions"].tobytes()
+    assert renderer.download_array("blasNodes").tobytes() == want_blas.tobytes(), "BLAS boxes, uploaded numbering"
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == want_inst.tobytes(), "world bounds of the mesh instances"
+    if policy == T.REBUILD_FORCE_REFIT:
+        assert _walk(nodes, idx) == _walk(_refit_numpy(arrs["tlasNodes"], arrs["tlasInstanceIndices"], want_inst), arrs["tlasInstanceIndices"])
+    else:
+        _check_valid_tlas(nodes, idx, inst)
+    arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = want_blas, inst, nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    _check_frames(orc, renderer, desc, cfg, w, h, spp)
+    # nothing changes when the same positions come again, and n = 0 is allowed
+    renderer.update_positions(first, new[first:first + cnt], T.REBUILD_FORCE_REFIT)
+    renderer.update_positions(0, np.zeros((0, 3), np.float32), T.REBUILD_FORCE_REFIT)
+    assert renderer.download_array("blasNodes").tobytes() == want_blas.tobytes()
+
+
+def test_update_positions_errors(renderer):
+    s = engine.Scene(); scenes.build_config4(s, 8, 8); renderer.commit(s)
+    n = len(s.arrays()["meshPositions"])
+    with pytest.raises(engine.HrtError, match="outside meshPositions"):
+        renderer.update_positions(n - 1, np.zeros((2, 3), np.float32))
+    with pytest.raises(engine.HrtError, match="outside meshPositions"):
+        renderer.update_positions(-1, np.zeros((1, 3), np.float32))
+    with pytest.raises(engine.HrtError, match="policy"):
+        renderer.update_positions(0, np.zeros((1, 3), np.float32), policy=9)
+    s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # no meshes: only the empty range exists
+    renderer.update_positions(0, np.zeros((0, 3), np.float32), T.REBUILD_FORCE_REFIT)
+    with pytest.raises(engine.HrtError, match="outside meshPositions"):
+        renderer.update_positions(0, np.zeros((1, 3), np.float32))
