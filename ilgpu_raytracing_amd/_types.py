@@ -93,6 +93,7 @@ SCENE_ARRAYS = [
 
 
 REBUILD_AUTO, REBUILD_FORCE_REFIT, REBUILD_FORCE_REBUILD = 0, 1, 2      # hrt_rebuild_policy = RebuildPolicy (BvhManager.cs:13-18)
+REBUILD_BLAS = 16                                                       # flag of hrt_scene_update_positions: new BLAS topology as well
 
 
 class BvhUpdateStats(C.Structure):    # hrt_bvh_update_stats

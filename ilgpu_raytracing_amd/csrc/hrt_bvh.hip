@@ -280,16 +280,31 @@ HRT_D F3 inst_centroid(const hrt_instance* in)
                0.5f * (in->worldBoundsMin.Z + in->worldBoundsMax.Z));
 }
 
+// what the LBVH is built over: the instances of the scene (TLAS) or the triangles of one mesh instance (BLAS)
+struct ItemSrc {
+    const hrt_instance* instances;      // TLAS: item i = instance i
+    const int32_t* triPrimIdx; const hrt_mesh_tri* tris; const hrt_float3* pos; int itemFirst;   // BLAS: item i = triangle triPrimIdx[itemFirst + i]
+    int n;
+};
+HRT_D int item_value(const ItemSrc& S, int i) { return S.instances ? i : S.triPrimIdx[S.itemFirst + i]; }
+HRT_D F3 item_centroid(const ItemSrc& S, int i)
+{
+    if (S.instances) return inst_centroid(S.instances + i);
+    const hrt_mesh_tri t = S.tris[S.triPrimIdx[S.itemFirst + i]];         // CenterOfTriangle, Scene.cs:607-614
+    const hrt_float3 a = S.pos[t.i0], b = S.pos[t.i1], c = S.pos[t.i2];
+    return mk3((a.X + b.X + c.X) / 3.f, (a.Y + b.Y + c.Y) / 3.f, (a.Z + b.Z + c.Z) / 3.f);
+}
+
 // floats as unsigned keys of the same order, so the bounds of all blocks meet in six atomicMin / atomicMax words
 HRT_D unsigned ord_key(float f) { const unsigned u = (unsigned)f2i(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 HRT_D float ord_float(unsigned k) { return i2f((int)((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k)); }
 
-__global__ void __launch_bounds__(kBlock) k_centroid_bounds(TlasDevice T)
+__global__ void __launch_bounds__(kBlock) k_centroid_bounds(TlasDevice T, ItemSrc S)
 {
     __shared__ float s[6][kBlock / 64];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    if (i < T.nI) { const F3 c = inst_centroid(T.instances + i); mn = c; mx = c; }
+    if (i < S.n) { const F3 c = item_centroid(S, i); mn = c; mx = c; }
     float v[6] = {mn.x, mn.y, mn.z, mx.x, mx.y, mx.z};
     for (int d = 32; d > 0; d >>= 1)
         for (int k = 0; k < 6; k++) { const float o = __shfl_xor(v[k], d); v[k] = k < 3 ? hrt_fmin(v[k], o) : hrt_fmax(v[k], o); }
@@ -322,42 +337,42 @@ HRT_D unsigned quant10(float c, float lo, float hi)
     return s >= 1023.f ? 1023u : (unsigned)(int)s;
 }
 
-__global__ void __launch_bounds__(kBlock) k_morton(TlasDevice T)
+__global__ void __launch_bounds__(kBlock) k_morton(TlasDevice T, ItemSrc S)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= T.nI) return;
-    const F3 c = inst_centroid(T.instances + i);
+    if (i >= S.n) return;
+    const F3 c = item_centroid(S, i);
     float cb[6];
     for (int k = 0; k < 6; k++) cb[k] = ord_float(T.cboundsKey[k]);
     const unsigned x = quant10(c.x, cb[0], cb[3]), y = quant10(c.y, cb[1], cb[4]), z = quant10(c.z, cb[2], cb[5]);
     T.keys[i] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
-    T.vals[i] = i;
+    T.vals[i] = item_value(S, i);
 }
 
-// leaf k = sorted slots [2k, 2k+2); its key is the key of its first slot; equal keys are told apart by k
-HRT_D int lbvh_delta(const unsigned* keys, int L, int a, int b)
+// leaf k = sorted slots [stride k, stride k + stride); its key is the key of its first slot; equal keys are told apart by k
+HRT_D int lbvh_delta(const unsigned* keys, int L, int stride, int a, int b)
 {
     if (b < 0 || b >= L) return -1;
-    const unsigned ka = keys[2 * a], kb = keys[2 * b];
+    const unsigned ka = keys[stride * a], kb = keys[stride * b];
     return ka != kb ? __clz((int)(ka ^ kb)) : 32 + __clz(a ^ b);
 }
 
 // one thread per inner node j of the L - 1 (Karras 2012): range of leaves, split, children
-__global__ void __launch_bounds__(kBlock) k_lbvh_inner(TlasDevice T, int L)
+__global__ void __launch_bounds__(kBlock) k_lbvh_inner(TlasDevice T, int L, int stride)
 {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= L - 1) return;
     const unsigned* keys = T.keysSorted;
-    const int d = lbvh_delta(keys, L, j, j + 1) - lbvh_delta(keys, L, j, j - 1) >= 0 ? 1 : -1;
-    const int dmin = lbvh_delta(keys, L, j, j - d);
+    const int d = lbvh_delta(keys, L, stride, j, j + 1) - lbvh_delta(keys, L, stride, j, j - 1) >= 0 ? 1 : -1;
+    const int dmin = lbvh_delta(keys, L, stride, j, j - d);
     int lmax = 2;
-    while (lbvh_delta(keys, L, j, j + lmax * d) > dmin) lmax <<= 1;
+    while (lbvh_delta(keys, L, stride, j, j + lmax * d) > dmin) lmax <<= 1;
     int l = 0;
-    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, L, j, j + (l + t) * d) > dmin) l += t;
+    for (int t = lmax >> 1; t >= 1; t >>= 1) if (lbvh_delta(keys, L, stride, j, j + (l + t) * d) > dmin) l += t;
     const int e = j + l * d;
-    const int dnode = lbvh_delta(keys, L, j, e);
+    const int dnode = lbvh_delta(keys, L, stride, j, e);
     int s = 0, t = l;
-    do { t = (t + 1) >> 1; if (lbvh_delta(keys, L, j, j + (s + t) * d) > dnode) s += t; } while (t > 1);
+    do { t = (t + 1) >> 1; if (lbvh_delta(keys, L, stride, j, j + (s + t) * d) > dnode) s += t; } while (t > 1);
     const int g = j + s * d + min(d, 0);
     const int a = min(j, e), b = max(j, e);
     T.rngA[j] = a; T.rngB[j] = b; T.split[j] = g;
@@ -497,6 +512,84 @@ __global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B)
     hrt_bvh_node* r = B.blasNodes + B.orig[i];
     r->boundsMin.X = q.lo.x; r->boundsMin.Y = q.lo.y; r->boundsMin.Z = q.lo.z;
     r->boundsMax.X = q.hi.x; r->boundsMax.Y = q.hi.y; r->boundsMax.Z = q.hi.z;
+    // links, in the numbering the reference-layout array uses (the uploaded one, or walk order after a rebuild)
+    const int cnt = (int)((unsigned)f2i(q.hi.w) >> 28), skip = f2i(q.hi.w) & kEnd, link = f2i(q.lo.w);
+    r->skipIndex = skip == kEnd ? -1 : B.orig[skip];
+    if (cnt > 0) { r->left = -1; r->right = -1; r->first = link; r->count = cnt; }
+    else
+    {
+        const int l = link & kEnd;
+        int rr = -1;
+        if (l != kEnd) { const int sk = node_skip(B.blas, l); if (sk != kEnd && sk != skip) rr = B.orig[sk]; }
+        r->left = l == kEnd ? -1 : B.orig[l]; r->right = rr; r->first = -1; r->count = 0;
+    }
+}
+
+// ------------------------------------------------------------------ BLAS rebuild of one mesh
+__global__ void __launch_bounds__(kBlock) k_blas_emit(TlasDevice T, BlasDevice B, MeshJob J, int L)
+{
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= J.nodeCap) return;
+    const int total = 2 * L - 1;
+    if (v >= total)
+    {   // the rest of the range the host's tree needed: owned by nobody
+        const int g = J.root + v;
+        B.parent[g] = -2; B.nchild[g] = 0; B.subend[g] = g + 1; B.orig[g] = g;
+        NodeQ z; z.lo = make_float4(0.f, 0.f, 0.f, i2f(kEnd)); z.hi = make_float4(0.f, 0.f, 0.f, i2f(kEnd));
+        B.blas[g] = z;
+        hrt_bvh_node* r = B.blasNodes + g;
+        r->boundsMin.X = r->boundsMin.Y = r->boundsMin.Z = 0.f; r->boundsMax.X = r->boundsMax.Y = r->boundsMax.Z = 0.f;
+        r->left = -1; r->right = -1; r->first = -1; r->count = 0; r->skipIndex = -1;
+        return;
+    }
+    const bool leaf = v >= L - 1;
+    const int k = v - (L - 1);
+    const int idx = L == 1 ? 0 : (leaf ? T.idxLeaf[k] : T.idxInt[v]);
+    const int leaves = leaf ? 1 : T.rngB[v] - T.rngA[v] + 1;
+    const int size = 2 * leaves - 1;
+    const int p = L == 1 ? -1 : (leaf ? T.parLeaf[k] : T.parInt[v]);
+    const int g = J.root + idx;
+    B.parent[g] = p < 0 ? -1 : J.root + T.idxInt[p];
+    B.subend[g] = g + size;
+    B.orig[g] = g;
+    const int skip = idx + size >= total ? kEnd : g + size;
+    NodeQ* q = B.blas + g;
+    if (leaf)
+    {
+        q->lo.w = i2f(J.leafBase + 4 * k);
+        q->hi.w = i2f(skip | (int)((unsigned)min(4, J.n - 4 * k) << 28));
+        B.nchild[g] = 0;
+    }
+    else
+    {
+        q->lo.w = i2f(g + 1);
+        q->hi.w = i2f(skip);
+        B.nchild[g] = 2;
+    }
+    if (v == 0) T.instances[J.inst].blasNodeCount = total;
+}
+
+// every lane of the FTri records of a rebuilt leaf region (the FTri half of validate_and_pack)
+__global__ void __launch_bounds__(kBlock) k_tri_records_full(BlasDevice B, int first, int n)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= n) return;
+    const int ti = B.triPrimIdx[first + j];
+    const hrt_mesh_tri t = B.meshTris[ti];
+    const hrt_float3 a = B.positions[t.i0], b = B.positions[t.i1], c = B.positions[t.i2];
+    const int mi = B.triMatIndex[ti];
+    hrt_material m;
+    if (B.nMaterials > 0) m = B.materials[mi];
+    else { m.Kd.X = m.Kd.Y = m.Kd.Z = 0.f; m.HasDiffuseMap = m.DiffuseTexIndex = m.Shading = 0; m.IOR = 0.f; m.HasAlphaMap = m.AlphaTexIndex = m.TwoSided = 0; m.AlphaCutoff = 0.f; }
+    const bool dmap = m.HasDiffuseMap != 0 && m.DiffuseTexIndex >= 0 && m.DiffuseTexIndex < B.texLen;
+    const bool amap = m.HasAlphaMap != 0 && m.AlphaTexIndex >= 0 && m.AlphaTexIndex < B.texLen;
+    const bool rejects_opaque = 1.0f < m.AlphaCutoff;
+    const int fl = ((dmap || amap || rejects_opaque) ? FT_TEXTURED : 0) | (m.TwoSided != 0 ? FT_TWOSIDED : 0);
+    FTri o;
+    o.v0 = make_float4(a.X, a.Y, a.Z, i2f(ti));
+    o.v1 = make_float4(b.X, b.Y, b.Z, i2f(mi));
+    o.v2 = make_float4(c.X, c.Y, c.Z, i2f(fl));
+    B.ftri[first + j] = o;
 }
 
 } // namespace
@@ -505,6 +598,32 @@ hipError_t blas_set_positions(const BlasDevice& B, int first, int n, const hrt_f
 {
     if (n <= 0) return hipSuccess;
     k_copy_positions<<<blocks_for(n), kBlock, 0, s>>>(B.positions + first, posDev, n);
+    return hipGetLastError();
+}
+
+hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const MeshJob& J, hipStream_t s)
+{
+    const int n = J.n;
+    if (n <= 0) return hipErrorInvalidValue;
+    const int L = (n + 3) / 4;
+    if (2 * L - 1 > J.nodeCap) return hipErrorInvalidValue;
+    ItemSrc S{};
+    S.triPrimIdx = B.triPrimIdx; S.tris = B.meshTris; S.pos = B.positions; S.itemFirst = J.itemFirst; S.n = n;
+    hipError_t e;
+    if ((e = hipMemsetAsync(T.cboundsKey, 0xFF, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(T.cboundsKey + 3, 0, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
+    k_centroid_bounds<<<blocks_for(n), kBlock, 0, s>>>(T, S);
+    k_morton<<<blocks_for(n), kBlock, 0, s>>>(T, S);
+    size_t bytes = T.sortTmpBytes;
+    e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)(B.triPrimIdxW + J.leafBase), n, 0, 30, s);
+    if (e != hipSuccess) return e;
+    if (L > 1)
+    {
+        k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L, 4);
+        k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
+    }
+    k_blas_emit<<<blocks_for(J.nodeCap), kBlock, 0, s>>>(T, B, J, L);
+    k_tri_records_full<<<blocks_for(n), kBlock, 0, s>>>(B, J.leafBase, n);
     return hipGetLastError();
 }
 
@@ -562,12 +681,14 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s)
     hipError_t e;
     if ((e = hipMemsetAsync(T.cboundsKey, 0xFF, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(T.cboundsKey + 3, 0, 3 * sizeof(unsigned), s)) != hipSuccess) return e;
-    k_centroid_bounds<<<blocks_for(n), kBlock, 0, s>>>(T);
-    k_morton<<<blocks_for(n), kBlock, 0, s>>>(T);
+    ItemSrc S{};
+    S.instances = T.instances; S.n = n;
+    k_centroid_bounds<<<blocks_for(n), kBlock, 0, s>>>(T, S);
+    k_morton<<<blocks_for(n), kBlock, 0, s>>>(T, S);
     size_t bytes = T.sortTmpBytes;
     e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)T.tlasInst, n, 0, 30, s);
     if (e != hipSuccess) return e;
-    k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L);
+    k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L, 2);
     k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
     k_lbvh_emit<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
     return hipGetLastError();

@@ -336,6 +336,9 @@ struct hrt_ctx {
     int tlas_leaves = 0;                       // reachable leaves of the TLAS in use
     bool tlas_on_device = false;               // the TLAS in use was refitted / rebuilt on the device (walk-order numbering)
     bool blas_refit_ok = false;                // hrt_scene_update_positions can refit every triangle-mesh BLAS
+    bool blas_rebuild_ok = false;              // ... and rebuild it (HRT_REBUILD_BLAS)
+    std::vector<MeshJob> mesh_jobs;
+    int max_mesh_items = 0;
     int64_t n_positions = 0;
     int64_t scene_count[15] = {};
     int width = 0, height = 0;
@@ -470,6 +473,8 @@ struct PackedHost {
     std::vector<int32_t> bparent, bnchild, bsubend, borig;   // BLAS nodes of triangle meshes, packed numbering: parent (-1 root, -2 not maintained),
                                                              // children, end of the subtree's index range, index in the uploaded numbering
     std::vector<int32_t> meshInst;                           // ids of the TriMesh instances whose BLAS is maintained
+    std::vector<MeshJob> meshJobs;                           // the same, with what a device-side rebuild of the BLAS needs
+    bool blas_rebuild_ok = true;                             // every mesh's leaves list their triangles in one region of triPrimIdx
     bool blas_refit_ok = true;                               // every TriMesh BLAS can be refitted on the device
     bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
     int reach_leaves = 0;     // reachable TLAS leaves
@@ -685,7 +690,27 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             }
             for (; at < nB; at++) { perm.assign(1, 0); pack_range(s->blasNodes, at, at + 1, perm, out.blas); }
         }
-        for (int64_t i = 0; i < nI; i++) if (s->instances[i].type == HRT_BLAS_TRIMESH && s->instances[i].blasNodeCount > 0) out.meshInst.push_back((int32_t)i);
+        for (int64_t i = 0; i < nI; i++)
+        {
+            const hrt_instance& in = s->instances[i];
+            if (in.type != HRT_BLAS_TRIMESH || in.blasNodeCount <= 0) continue;
+            out.meshInst.push_back((int32_t)i);
+            // region of triPrimIdx the leaves of this BLAS point into (the builder appends it behind the item list, Scene.cs:439-440)
+            int64_t lo = INT64_MAX, hi = -1, sum = 0;
+            for (int64_t k = in.blasRoot; k < (int64_t)in.blasRoot + in.blasNodeCount; k++)
+            {
+                const hrt_bvh_node& b = s->blasNodes[k];
+                if (b.count <= 0) continue;
+                lo = std::min<int64_t>(lo, b.first); hi = std::max<int64_t>(hi, (int64_t)b.first + b.count); sum += b.count;
+            }
+            const int64_t n = in.primIndexCount;
+            MeshJob J; J.inst = (int)i; J.root = in.blasRoot; J.nodeCap = in.blasNodeCount; J.leafBase = (int)lo; J.n = (int)n; J.itemFirst = in.primIndexFirst;
+            const bool items_ok = n > 0 && in.primIndexFirst >= 0 && (int64_t)in.primIndexFirst + n <= nTP;
+            const bool region_ok = hi - lo == n && sum == n && (lo >= (int64_t)in.primIndexFirst + n || hi <= in.primIndexFirst);
+            if (!items_ok || !region_ok || 2 * ((n + 3) / 4) - 1 > in.blasNodeCount) out.blas_rebuild_ok = false;
+            for (const MeshJob& o : out.meshJobs) if (o.root == J.root || !(J.leafBase >= o.leafBase + o.n || o.leafBase >= J.leafBase + J.n)) out.blas_rebuild_ok = false;
+            out.meshJobs.push_back(J);
+        }
     }
     if (nT == 0)
     {   // reference semantics of the zeroed 1-element TLAS: node 0 has count 0, left 0 -> loops forever on a hit;
@@ -1246,6 +1271,10 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->tlas_leaves = ph.reach_leaves;
     c->tlas_on_device = false;
     c->blas_refit_ok = ph.blas_refit_ok && ph.ok;
+    c->blas_rebuild_ok = c->blas_refit_ok && ph.blas_rebuild_ok;
+    c->mesh_jobs = ph.meshJobs;
+    c->max_mesh_items = 0;
+    for (const MeshJob& J : ph.meshJobs) c->max_mesh_items = std::max(c->max_mesh_items, J.n);
     c->n_positions = s->n_meshPositions;
     for (int i = 0; i < 15; i++) c->scene_count[i] = cnt[i];
     // room for a TLAS rebuilt on the device over all instances (leaves of two: hrt_bvh.hpp)
@@ -1321,6 +1350,8 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
                 }
                 BlasDevice& B = d.bl;
                 B.blasNodes = (hrt_bvh_node*)d.scene[3]; B.triPrimIdx = (const int32_t*)d.scene[6]; B.meshTris = (const hrt_mesh_tri*)d.scene[8];
+                B.triPrimIdxW = (int32_t*)d.scene[6]; B.triMatIndex = (const int32_t*)d.scene[11]; B.materials = (const hrt_material*)d.scene[12];
+                B.nMaterials = (int)s->n_materials; B.texLen = (int)(s->n_texInfos > 0 ? s->n_texInfos : 1);
                 B.positions = (hrt_float3*)d.scene[7]; B.blas = (NodeQ*)d.packed[2]; B.ftri = (FTri*)d.packed[3];
                 B.parent = (int*)d.blaux[0]; B.nchild = (int*)d.blaux[1]; B.subend = (int*)d.blaux[2]; B.orig = (int*)d.blaux[3]; B.arrive = (int*)d.blaux[4];
                 B.nB = (int)s->n_blasNodes; B.nSlots = (int)s->n_triPrimIdx; B.directMax = 63;
@@ -1347,7 +1378,7 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 {
     if (d.tlscratch) return HRT_OK;
     TlasDevice& T = d.tl;
-    const size_t n = (size_t)std::max(T.nI, 1), L = (n + 1) / 2;
+    const size_t n = (size_t)std::max(std::max(T.nI, c->max_mesh_items), 1), L = (n + 1) / 2;
     const size_t sortBytes = tlas_sort_temp_bytes((int)n);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t total = 3 * up(n * 4) + 7 * up(L * 4) + up(6 * 4) + up(sortBytes);
@@ -1495,8 +1526,18 @@ int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_f
         return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_positions: vertex range outside meshPositions");
     if (!c->blas_refit_ok)
         return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: a triangle-mesh BLAS of this scene cannot be refitted (shared or overlapping node ranges, unreachable nodes)");
+    const bool rebuildBlas = policy >= 0 && (policy & HRT_REBUILD_BLAS) != 0;
+    if (policy >= 0) policy &= ~HRT_REBUILD_BLAS;
+    if (rebuildBlas && !c->blas_rebuild_ok)
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: a triangle-mesh BLAS of this scene cannot be rebuilt on the device (its leaves do not list their triangles in one region of triPrimIdx)");
     return apply_update(c, policy, "hrt_scene_update_positions", [&](DeviceState& d, std::vector<void*>&) -> int {
         if (n > 0) HIPCHK(c, hipMemcpyAsync((hrt_float3*)d.scene[7] + first, positions, (size_t)n * sizeof(hrt_float3), hipMemcpyHostToDevice, d.stream));
+        if (rebuildBlas && !c->mesh_jobs.empty())
+        {
+            int rc2 = ensure_lbvh_scratch(c, d);
+            if (rc2 != HRT_OK) return rc2;
+            for (const MeshJob& J : c->mesh_jobs) HIPCHK(c, blas_rebuild_mesh(d.tl, d.bl, J, d.stream));
+        }
         if (d.bl.nSlots > 0) HIPCHK(c, blas_refit(d.bl, d.stream));
         HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[5], d.n_mesh_inst, d.stream));
         return HRT_OK;

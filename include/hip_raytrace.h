@@ -183,7 +183,8 @@ int  hrt_scene_upload(hrt_ctx* ctx, const hrt_scene_desc* scene);
  * updated this way is numbered in walk order; hrt_scene_download_tlas returns it in the reference's layout.
  * A different tree visits the same primitives in another order: results change only where two primitives are
  * hit at bit-equal distance (DESIGN.md "inner nodes only accelerate"). */
-enum hrt_rebuild_policy { HRT_REBUILD_AUTO = 0, HRT_REBUILD_FORCE_REFIT = 1, HRT_REBUILD_FORCE_REBUILD = 2 };
+enum hrt_rebuild_policy { HRT_REBUILD_AUTO = 0, HRT_REBUILD_FORCE_REFIT = 1, HRT_REBUILD_FORCE_REBUILD = 2,
+                          HRT_REBUILD_BLAS = 16 /* flag for hrt_scene_update_positions, see there */ };
 
 typedef struct hrt_bvh_update_stats {
     int32_t action;           /* HRT_REBUILD_FORCE_REFIT or HRT_REBUILD_FORCE_REBUILD: what was done          */
@@ -204,7 +205,12 @@ int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32
  * every triangle-mesh BLAS keeps its topology and gets its triangle records and boxes recomputed bottom-up on the device
  * (BoundsOfTriangle over the items of each node, Scene.cs:423-429,597-605), the world bounds of the mesh instances are
  * re-derived from the new root boxes (TransformAABB, Scene.cs:560-580), and the TLAS is refitted / rebuilt per `policy`
- * as in hrt_scene_update_instances.  Sphere BLASes are untouched.  Blocking; every device of the context is updated. */
+ * as in hrt_scene_update_instances.  policy | HRT_REBUILD_BLAS first gives every triangle-mesh BLAS a new topology for the
+ * new positions: a Morton-order LBVH over its triangles with leaves of <= 4 like the reference's BLAS, built on the device
+ * into the node range and the leaf region of triPrimIdx the mesh already owns (blasNodeCount of its instance shrinks to
+ * the new node count).  Another BLAS visits triangles in another order: pixels where two triangles are hit at bit-equal
+ * distance (shared edges) may change, exactly as they would under a different host builder.
+ * Sphere BLASes are untouched.  Blocking; every device of the context is updated. */
 int  hrt_scene_update_positions(hrt_ctx* ctx, int64_t first_vertex, int64_t n, const hrt_float3* positions,
                                 int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
 

@@ -431,3 +431,61 @@ def test_update_positions_errors(renderer):
     renderer.update_positions(0, np.zeros((0, 3), np.float32), T.REBUILD_FORCE_REFIT)
     with pytest.raises(engine.HrtError, match="outside meshPositions"):
         renderer.update_positions(0, np.zeros((1, 3), np.float32))
+
+
+@pytest.mark.parametrize("name", list(MESH_SCENES))
+def test_deformed_meshes_get_a_new_blas_on_the_device(orc, renderer, name):
+    """policy | REBUILD_BLAS: every triangle-mesh BLAS is rebuilt (LBVH, leaves of <= 4) inside the node range and the leaf
+    region it already owns.  The result is checked as a tree, its boxes against the numpy restatement, and frames against the
+    oracle on the downloaded arrays."""
+    builder, cfg, w, h, spp = MESH_SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    arrs = s.arrays()
+    pos = np.stack([arrs["meshPositions"][f] for f in "XYZ"], axis=1)
+    new = (pos * (1.0 + 0.1 * np.sin(6.0 * pos[:, [2, 0, 1]] + 0.5))).astype(np.float32)
+    st = renderer.update_positions(0, new, T.REBUILD_FORCE_REFIT | T.REBUILD_BLAS)
+    assert st.action == T.REBUILD_FORCE_REFIT
+    got = {k: renderer.download_array(k) for k in ("meshPositions", "blasNodes", "triPrimIdx")}
+    nodes, idx, inst = _download(renderer)
+    for k, f in enumerate("XYZ"):
+        arrs["meshPositions"][f] = new[:, k]
+    assert got["meshPositions"].tobytes() == arrs["meshPositions"].tobytes()
+    host_inst = arrs["instances"]
+    for ii in range(len(inst)):
+        a, b = inst[ii], host_inst[ii]
+        if b["type"] != 2:
+            assert a.tobytes() == b.tobytes()
+            lo, hi = int(b["blasRoot"]), int(b["blasRoot"] + b["blasNodeCount"])
+            assert got["blasNodes"][lo:hi].tobytes() == arrs["blasNodes"][lo:hi].tobytes(), "sphere BLASes are untouched"
+            continue
+        n_items = int(b["primIndexCount"])
+        leaves = (n_items + 3) // 4
+        assert a["blasRoot"] == b["blasRoot"] and a["blasNodeCount"] == 2 * leaves - 1 <= b["blasNodeCount"]
+        items = sorted(arrs["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist())
+        assert got["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist() == arrs["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist()
+        # walk the new BLAS: every node once, leaves of <= 4, every triangle of the mesh in exactly one leaf
+        root, cur, seen, tri = int(a["blasRoot"]), int(a["blasRoot"]), 0, []
+        while cur != -1:
+            nd = got["blasNodes"][cur]
+            seen += 1
+            assert seen <= a["blasNodeCount"]
+            if nd["count"] > 0:
+                assert nd["count"] <= 4
+                tri.extend(got["triPrimIdx"][nd["first"]:nd["first"] + nd["count"]].tolist())
+                cur = int(nd["skipIndex"])
+            else:
+                assert nd["left"] == cur + 1
+                cur = int(nd["left"])
+        assert seen == a["blasNodeCount"] and sorted(tri) == items
+    arrs["blasNodes"], arrs["triPrimIdx"], arrs["instances"] = got["blasNodes"], got["triPrimIdx"], inst
+    want_blas, want_inst = _refit_blas_numpy(arrs)
+    assert want_blas.tobytes() == got["blasNodes"].tobytes() and want_inst.tobytes() == inst.tobytes()
+    arrs["tlasNodes"], arrs["tlasInstanceIndices"] = nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    _check_frames(orc, renderer, desc, cfg, w, h, spp)
+    # deterministic, and a refit afterwards keeps the new topology
+    renderer.update_positions(0, new, T.REBUILD_FORCE_REFIT | T.REBUILD_BLAS)
+    assert renderer.download_array("blasNodes").tobytes() == got["blasNodes"].tobytes()
+    assert renderer.download_array("triPrimIdx").tobytes() == got["triPrimIdx"].tobytes()
+    renderer.update_positions(0, new[:0], T.REBUILD_FORCE_REFIT)
+    assert renderer.download_array("blasNodes").tobytes() == got["blasNodes"].tobytes()
