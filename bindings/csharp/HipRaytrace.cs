@@ -83,7 +83,9 @@ namespace ILGPU_Raytracing.Engine
         [DllImport(Lib)] public static extern void hrt_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr hrt_last_error(IntPtr ctx);
         [DllImport(Lib)] public static extern int hrt_scene_upload(IntPtr ctx, HrtSceneDesc* scene);
-        // BvhManager.BuildOrRefit(scene, policy) for moved instances: policy = (int)RebuildPolicy (Auto 0, ForceRefit 1, ForceRebuild 2)
+        // BvhManager.BuildOrRefit(scene, policy) for moved instances: policy = (int)RebuildPolicy (Auto 0, ForceRefit 1, ForceRebuild 2);
+        // hrt_scene_update_positions also takes policy | HRT_REBUILD_BLAS (16): new BLAS topology for every mesh
+        public const int HRT_REBUILD_BLAS = 16;
         [DllImport(Lib)] public static extern int hrt_scene_update_instances(IntPtr ctx, int* instanceIds, int n, Affine3x4* objectToWorld, int policy, HrtBvhUpdateStats* stats);
         [DllImport(Lib)] public static extern int hrt_scene_update_positions(IntPtr ctx, long firstVertex, long n, Float3* positions, int policy, HrtBvhUpdateStats* stats);
         [DllImport(Lib)] public static extern int hrt_scene_download_array(IntPtr ctx, int dev, int array, void* dst, long cap, long* count);

@@ -39,6 +39,14 @@ for cid in [int(c) for c in args.configs.split(",")]:
         t = time.perf_counter(); st = r.update_positions(0, new, T.REBUILD_FORCE_REFIT); best = min(best, time.perf_counter() - t)
     row["device_refit_ms_wall_with_h2d"], row["device_refit_ms_kernels"] = best * 1e3, st.device_ms
     row["frame_ms_after_refit"] = frame_ms(p)
+    best = 1e9
+    for _ in range(5):
+        t = time.perf_counter(); st = r.update_positions(0, new, T.REBUILD_FORCE_REFIT | T.REBUILD_BLAS); best = min(best, time.perf_counter() - t)
+    row["device_blas_rebuild_ms_wall_with_h2d"], row["device_blas_rebuild_ms_kernels"] = best * 1e3, st.device_ms
+    row["frame_ms_after_blas_rebuild"] = frame_ms(p)
+    # the undeformed mesh under a device-built BLAS: tree quality of the LBVH against the reference's median split
+    r.update_positions(0, pos, T.REBUILD_FORCE_REFIT | T.REBUILD_BLAS)
+    row["frame_ms_undeformed_device_blas"] = frame_ms(p)
     rows.append(row)
     print(json.dumps(row), flush=True)
 if args.out:
