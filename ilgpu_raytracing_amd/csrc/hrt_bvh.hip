@@ -344,7 +344,10 @@ __global__ void __launch_bounds__(kBlock) k_morton(TlasDevice T, ItemSrc S)
     const F3 c = item_centroid(S, i);
     float cb[6];
     for (int k = 0; k < 6; k++) cb[k] = ord_float(T.cboundsKey[k]);
-    const unsigned x = quant10(c.x, cb[0], cb[3]), y = quant10(c.y, cb[1], cb[4]), z = quant10(c.z, cb[2], cb[5]);
+    // cubic cells: every axis is cut with the pitch of the longest one, so a flat scene (a terrain, a city) is not sliced
+    // along its thin axis at the top of the tree
+    const float ext = hrt_fmax(cb[3] - cb[0], hrt_fmax(cb[4] - cb[1], cb[5] - cb[2]));
+    const unsigned x = quant10(c.x, cb[0], cb[0] + ext), y = quant10(c.y, cb[1], cb[1] + ext), z = quant10(c.z, cb[2], cb[2] + ext);
     T.keys[i] = (spread3(x) << 2) | (spread3(y) << 1) | spread3(z);
     T.vals[i] = item_value(S, i);
 }
@@ -526,38 +529,76 @@ __global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B)
 }
 
 // ------------------------------------------------------------------ BLAS rebuild of one mesh
-__global__ void __launch_bounds__(kBlock) k_blas_emit(TlasDevice T, BlasDevice B, MeshJob J, int L)
+// Karras' tree over the single triangles (n leaves, n - 1 inner nodes); a node is EMITTED as a leaf when its subtree holds at
+// most `limit` triangles and its parent's more, as an inner node when it holds more.  Leaves therefore never straddle a
+// split of the hierarchy (groups of four consecutive triangles in Morton order did, and the few that straddled a top-level
+// split had boxes across the whole mesh).  Emitted leaves partition the sorted triangles into runs, so with
+// S[i] = leaves starting before triangle i the emitted subtree of a node over [a, b] has 2 (S[b + 1] - S[a]) - 1 nodes:
+// walk-order indices and skip links again come from the root path alone.
+HRT_D int knode_size(const TlasDevice& T, int n, int v) { return v < n - 1 ? T.rngB[v] - T.rngA[v] + 1 : 1; }     // v >= n - 1: single triangle v - (n - 1)
+HRT_D int knode_parent(const TlasDevice& T, int n, int v) { return v < n - 1 ? T.parInt[v] : T.parLeaf[v - (n - 1)]; }
+HRT_D int knode_first(const TlasDevice& T, int n, int v) { return v < n - 1 ? T.rngA[v] : v - (n - 1); }
+
+// leafCounts[t] = leaves of the tree under leaf-size limit t, t = 4..14
+__global__ void __launch_bounds__(kBlock) k_leaf_counts(TlasDevice T, int n)
+{
+    __shared__ int s[16];
+    if (threadIdx.x < 16) s[threadIdx.x] = 0;
+    __syncthreads();
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v < 2 * n - 1)
+    {
+        const int size = knode_size(T, n, v);
+        const int p = n == 1 ? -1 : knode_parent(T, n, v);
+        const int psize = p < 0 ? 0x7FFFFFFF : knode_size(T, n, p);
+        for (int t = max(size, 4); t <= 14 && t < psize; t++) atomicAdd(&s[t], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x >= 4 && threadIdx.x <= 14 && s[threadIdx.x]) atomicAdd(T.leafCounts + threadIdx.x, s[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(kBlock) k_mark_leaves(TlasDevice T, int n, int limit)
 {
     const int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= J.nodeCap) return;
-    const int total = 2 * L - 1;
-    if (v >= total)
-    {   // the rest of the range the host's tree needed: owned by nobody
-        const int g = J.root + v;
-        B.parent[g] = -2; B.nchild[g] = 0; B.subend[g] = g + 1; B.orig[g] = g;
-        NodeQ z; z.lo = make_float4(0.f, 0.f, 0.f, i2f(kEnd)); z.hi = make_float4(0.f, 0.f, 0.f, i2f(kEnd));
-        B.blas[g] = z;
-        hrt_bvh_node* r = B.blasNodes + g;
-        r->boundsMin.X = r->boundsMin.Y = r->boundsMin.Z = 0.f; r->boundsMax.X = r->boundsMax.Y = r->boundsMax.Z = 0.f;
-        r->left = -1; r->right = -1; r->first = -1; r->count = 0; r->skipIndex = -1;
-        return;
+    if (v >= 2 * n - 1) return;
+    const int size = knode_size(T, n, v);
+    const int p = n == 1 ? -1 : knode_parent(T, n, v);
+    if (size <= limit && (p < 0 || knode_size(T, n, p) > limit)) T.lstart[knode_first(T, n, v)] = 1;
+}
+
+__global__ void __launch_bounds__(kBlock) k_blas_emit(TlasDevice T, BlasDevice B, MeshJob J, int limit)
+{
+    const int n = J.n;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= 2 * n - 1) return;
+    const int size = knode_size(T, n, v);
+    int p = n == 1 ? -1 : knode_parent(T, n, v);
+    const bool leaf = size <= limit;
+    if (leaf && p >= 0 && knode_size(T, n, p) <= limit) return;          // inside a collapsed subtree
+    const int a = knode_first(T, n, v), b = a + size - 1;
+    const int* S = T.lsum;
+    // root path: +1 per left edge, +1 + (emitted nodes of the left sibling) per right edge
+    int idx = 0, start = a, parentDelta = 0;
+    for (int q = p; q >= 0; q = T.parInt[q])
+    {
+        const int g = T.split[q], qa = T.rngA[q];
+        const int d = start == g + 1 ? 2 * (S[g + 1] - S[qa]) : 1;
+        if (q == p) parentDelta = d;
+        idx += d;
+        start = qa;
     }
-    const bool leaf = v >= L - 1;
-    const int k = v - (L - 1);
-    const int idx = L == 1 ? 0 : (leaf ? T.idxLeaf[k] : T.idxInt[v]);
-    const int leaves = leaf ? 1 : T.rngB[v] - T.rngA[v] + 1;
-    const int size = 2 * leaves - 1;
-    const int p = L == 1 ? -1 : (leaf ? T.parLeaf[k] : T.parInt[v]);
+    const int total = 2 * S[n] - 1;
+    const int emitted = 2 * (S[b + 1] - S[a]) - 1;
     const int g = J.root + idx;
-    B.parent[g] = p < 0 ? -1 : J.root + T.idxInt[p];
-    B.subend[g] = g + size;
+    B.parent[g] = p < 0 ? -1 : g - parentDelta;
+    B.subend[g] = g + emitted;
     B.orig[g] = g;
-    const int skip = idx + size >= total ? kEnd : g + size;
+    const int skip = idx + emitted >= total ? kEnd : g + emitted;
     NodeQ* q = B.blas + g;
     if (leaf)
     {
-        q->lo.w = i2f(J.leafBase + 4 * k);
-        q->hi.w = i2f(skip | (int)((unsigned)min(4, J.n - 4 * k) << 28));
+        q->lo.w = i2f(J.leafBase + a);
+        q->hi.w = i2f(skip | (int)((unsigned)size << 28));
         B.nchild[g] = 0;
     }
     else
@@ -566,7 +607,22 @@ __global__ void __launch_bounds__(kBlock) k_blas_emit(TlasDevice T, BlasDevice B
         q->hi.w = i2f(skip);
         B.nchild[g] = 2;
     }
-    if (v == 0) T.instances[J.inst].blasNodeCount = total;
+    if (p < 0) T.instances[J.inst].blasNodeCount = total;
+}
+
+// the rest of the range the host's tree needed: owned by nobody
+__global__ void __launch_bounds__(kBlock) k_blas_tail(TlasDevice T, BlasDevice B, MeshJob J)
+{
+    const int total = 2 * T.lsum[J.n] - 1;
+    const int v = total + blockIdx.x * kBlock + threadIdx.x;
+    if (v >= J.nodeCap) return;
+    const int g = J.root + v;
+    B.parent[g] = -2; B.nchild[g] = 0; B.subend[g] = g + 1; B.orig[g] = g;
+    NodeQ z; z.lo = make_float4(0.f, 0.f, 0.f, i2f(kEnd)); z.hi = make_float4(0.f, 0.f, 0.f, i2f(kEnd));
+    B.blas[g] = z;
+    hrt_bvh_node* r = B.blasNodes + g;
+    r->boundsMin.X = r->boundsMin.Y = r->boundsMin.Z = 0.f; r->boundsMax.X = r->boundsMax.Y = r->boundsMax.Z = 0.f;
+    r->left = -1; r->right = -1; r->first = -1; r->count = 0; r->skipIndex = -1;
 }
 
 // every lane of the FTri records of a rebuilt leaf region (the FTri half of validate_and_pack)
@@ -601,12 +657,17 @@ hipError_t blas_set_positions(const BlasDevice& B, int first, int n, const hrt_f
     return hipGetLastError();
 }
 
-hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const MeshJob& J, hipStream_t s)
+size_t tlas_iscan_temp_bytes(int n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int*)nullptr, (int*)nullptr, n, (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const MeshJob& J, hipStream_t s, int* leafLimitOut)
 {
     const int n = J.n;
     if (n <= 0) return hipErrorInvalidValue;
-    const int L = (n + 3) / 4;
-    if (2 * L - 1 > J.nodeCap) return hipErrorInvalidValue;
     ItemSrc S{};
     S.triPrimIdx = B.triPrimIdx; S.tris = B.meshTris; S.pos = B.positions; S.itemFirst = J.itemFirst; S.n = n;
     hipError_t e;
@@ -617,12 +678,23 @@ hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const Mes
     size_t bytes = T.sortTmpBytes;
     e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)(B.triPrimIdxW + J.leafBase), n, 0, 30, s);
     if (e != hipSuccess) return e;
-    if (L > 1)
-    {
-        k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L, 4);
-        k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
-    }
-    k_blas_emit<<<blocks_for(J.nodeCap), kBlock, 0, s>>>(T, B, J, L);
+    if (n > 1) k_lbvh_inner<<<blocks_for(n - 1), kBlock, 0, s>>>(T, n, 1);
+    // the smallest leaf-size limit whose tree fits the node range of the mesh
+    int counts[16];
+    if ((e = hipMemsetAsync(T.leafCounts, 0, 16 * sizeof(int), s)) != hipSuccess) return e;
+    k_leaf_counts<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n);
+    if ((e = hipMemcpyAsync(counts, T.leafCounts, sizeof(counts), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    int limit = 4;
+    while (limit < 14 && 2 * counts[limit] - 1 > J.nodeCap) limit++;
+    if (2 * counts[limit] - 1 > J.nodeCap) return hipErrorInvalidValue;
+    if (leafLimitOut) *leafLimitOut = limit;
+    if ((e = hipMemsetAsync(T.lstart, 0, (size_t)(n + 1) * sizeof(int), s)) != hipSuccess) return e;
+    k_mark_leaves<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n, limit);
+    bytes = T.iscanTmpBytes;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(T.iscanTmp, bytes, (const int*)T.lstart, T.lsum, n + 1, s)) != hipSuccess) return e;
+    k_blas_emit<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, B, J, limit);
+    k_blas_tail<<<blocks_for(J.nodeCap), kBlock, 0, s>>>(T, B, J);
     k_tri_records_full<<<blocks_for(n), kBlock, 0, s>>>(B, J.leafBase, n);
     return hipGetLastError();
 }

@@ -655,6 +655,15 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         }
         else
         {
+            // who owns each range: bit 0 a triangle mesh, bit 1 anything else
+            std::vector<uint8_t> rangeKind(ranges.size(), 0);
+            for (int64_t i = 0; i < nI; i++)
+            {
+                const hrt_instance& in = s->instances[i];
+                if (in.blasNodeCount <= 0) continue;
+                const auto it = std::lower_bound(ranges.begin(), ranges.end(), std::make_pair((int64_t)in.blasRoot, (int64_t)in.blasRoot + in.blasNodeCount));
+                rangeKind[(size_t)(it - ranges.begin())] |= in.type == HRT_BLAS_TRIMESH ? 1 : 2;
+            }
             int64_t at = 0;
             for (const auto& r : ranges)
             {
@@ -663,10 +672,8 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
                 pack_range(s->blasNodes, r.first, r.second, perm, out.blas);
                 at = r.second;
                 // maintenance arrays for the BLAS of a triangle mesh (device refit after a vertex update, hrt_bvh.hpp)
-                bool mesh = false, other = false;
-                for (int64_t i = 0; i < nI; i++)
-                    if (s->instances[i].blasNodeCount > 0 && s->instances[i].blasRoot == r.first && (int64_t)s->instances[i].blasRoot + s->instances[i].blasNodeCount == r.second)
-                        (s->instances[i].type == HRT_BLAS_TRIMESH ? mesh : other) = true;
+                const uint8_t kind = rangeKind[(size_t)(&r - ranges.data())];
+                const bool mesh = (kind & 1) != 0, other = (kind & 2) != 0;
                 if (!mesh) continue;
                 if (other || reach != (int32_t)(r.second - r.first)) { out.blas_refit_ok = false; continue; }   // shared with a sphere set, unreachable nodes or builder numbering
                 auto cntq = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.blas[(size_t)i].hi.w) >> 28); };
@@ -707,9 +714,15 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             MeshJob J; J.inst = (int)i; J.root = in.blasRoot; J.nodeCap = in.blasNodeCount; J.leafBase = (int)lo; J.n = (int)n; J.itemFirst = in.primIndexFirst;
             const bool items_ok = n > 0 && in.primIndexFirst >= 0 && (int64_t)in.primIndexFirst + n <= nTP;
             const bool region_ok = hi - lo == n && sum == n && (lo >= (int64_t)in.primIndexFirst + n || hi <= in.primIndexFirst);
-            if (!items_ok || !region_ok || 2 * ((n + 3) / 4) - 1 > in.blasNodeCount) out.blas_rebuild_ok = false;
-            for (const MeshJob& o : out.meshJobs) if (o.root == J.root || !(J.leafBase >= o.leafBase + o.n || o.leafBase >= J.leafBase + J.n)) out.blas_rebuild_ok = false;
+            if (!items_ok || !region_ok || 2 * ((n + 13) / 14) - 1 > in.blasNodeCount) out.blas_rebuild_ok = false;
             out.meshJobs.push_back(J);
+        }
+        {   // two meshes must not share a node range or a leaf region
+            std::vector<std::pair<int, int>> byRoot, byLeaf;
+            for (const MeshJob& J : out.meshJobs) { byRoot.emplace_back(J.root, J.nodeCap); byLeaf.emplace_back(J.leafBase, J.n); }
+            std::sort(byRoot.begin(), byRoot.end()); std::sort(byLeaf.begin(), byLeaf.end());
+            for (size_t k = 1; k < byRoot.size(); k++)
+                if (byRoot[k].first < byRoot[k - 1].first + byRoot[k - 1].second || byLeaf[k].first < byLeaf[k - 1].first + byLeaf[k - 1].second) out.blas_rebuild_ok = false;
         }
     }
     if (nT == 0)
@@ -1378,10 +1391,11 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 {
     if (d.tlscratch) return HRT_OK;
     TlasDevice& T = d.tl;
-    const size_t n = (size_t)std::max(std::max(T.nI, c->max_mesh_items), 1), L = (n + 1) / 2;
-    const size_t sortBytes = tlas_sort_temp_bytes((int)n);
+    const size_t n = (size_t)std::max(std::max(T.nI, c->max_mesh_items), 1);
+    const size_t L = std::max<size_t>(((size_t)std::max(T.nI, 1) + 1) / 2, (size_t)c->max_mesh_items) + 1;      // TLAS: leaves of two; BLAS: Karras over single triangles
+    const size_t sortBytes = tlas_sort_temp_bytes((int)n), iscanBytes = tlas_iscan_temp_bytes((int)c->max_mesh_items + 1);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t total = 3 * up(n * 4) + 7 * up(L * 4) + up(6 * 4) + up(sortBytes);
+    const size_t total = 3 * up(n * 4) + 7 * up(L * 4) + up(6 * 4) + up(sortBytes) + 2 * up((n + 1) * 4) + up(16 * 4) + up(iscanBytes);
     HIPCHK(c, hipMalloc(&d.tlscratch, total));
     char* p = (char*)d.tlscratch;
     auto take = [&](size_t b) { char* r = p; p += up(b); return (void*)r; };
@@ -1389,6 +1403,8 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
     T.rngA = (int*)take(L * 4); T.rngB = (int*)take(L * 4); T.split = (int*)take(L * 4); T.parInt = (int*)take(L * 4);
     T.parLeaf = (int*)take(L * 4); T.idxInt = (int*)take(L * 4); T.idxLeaf = (int*)take(L * 4);
     T.cboundsKey = (unsigned*)take(6 * 4);
+    T.lstart = (int*)take((n + 1) * 4); T.lsum = (int*)take((n + 1) * 4); T.leafCounts = (int*)take(16 * 4);
+    T.iscanTmp = take(iscanBytes); T.iscanTmpBytes = iscanBytes;
     T.sortTmp = take(sortBytes); T.sortTmpBytes = sortBytes;
     return HRT_OK;
 }
@@ -1536,7 +1552,7 @@ int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_f
         {
             int rc2 = ensure_lbvh_scratch(c, d);
             if (rc2 != HRT_OK) return rc2;
-            for (const MeshJob& J : c->mesh_jobs) HIPCHK(c, blas_rebuild_mesh(d.tl, d.bl, J, d.stream));
+            for (const MeshJob& J : c->mesh_jobs) HIPCHK(c, blas_rebuild_mesh(d.tl, d.bl, J, d.stream, nullptr));
         }
         if (d.bl.nSlots > 0) HIPCHK(c, blas_refit(d.bl, d.stream));
         HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[5], d.n_mesh_inst, d.stream));

@@ -435,8 +435,8 @@ def test_update_positions_errors(renderer):
 
 @pytest.mark.parametrize("name", list(MESH_SCENES))
 def test_deformed_meshes_get_a_new_blas_on_the_device(orc, renderer, name):
-    """policy | REBUILD_BLAS: every triangle-mesh BLAS is rebuilt (LBVH, leaves of <= 4) inside the node range and the leaf
-    region it already owns.  The result is checked as a tree, its boxes against the numpy restatement, and frames against the
+    """policy | REBUILD_BLAS: every triangle-mesh BLAS is rebuilt (LBVH; subtrees of <= 4 triangles become leaves, more only
+    if the tree would not fit otherwise) inside the node range and the leaf region it already owns.  The result is checked as a tree, its boxes against the numpy restatement, and frames against the
     oracle on the downloaded arrays."""
     builder, cfg, w, h, spp = MESH_SCENES[name]
     s = engine.Scene(); builder(s); renderer.commit(s)
@@ -459,18 +459,18 @@ def test_deformed_meshes_get_a_new_blas_on_the_device(orc, renderer, name):
             assert got["blasNodes"][lo:hi].tobytes() == arrs["blasNodes"][lo:hi].tobytes(), "sphere BLASes are untouched"
             continue
         n_items = int(b["primIndexCount"])
-        leaves = (n_items + 3) // 4
-        assert a["blasRoot"] == b["blasRoot"] and a["blasNodeCount"] == 2 * leaves - 1 <= b["blasNodeCount"]
+        assert a["blasRoot"] == b["blasRoot"] and 0 < a["blasNodeCount"] <= b["blasNodeCount"] and a["blasNodeCount"] % 2 == 1
         items = sorted(arrs["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist())
         assert got["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist() == arrs["triPrimIdx"][b["primIndexFirst"]:b["primIndexFirst"] + n_items].tolist()
         # walk the new BLAS: every node once, leaves of <= 4, every triangle of the mesh in exactly one leaf
-        root, cur, seen, tri = int(a["blasRoot"]), int(a["blasRoot"]), 0, []
+        root, cur, seen, tri, big = int(a["blasRoot"]), int(a["blasRoot"]), 0, [], 0
         while cur != -1:
             nd = got["blasNodes"][cur]
             seen += 1
             assert seen <= a["blasNodeCount"]
             if nd["count"] > 0:
-                assert nd["count"] <= 4
+                assert nd["count"] <= 14
+                big = max(big, int(nd["count"]))
                 tri.extend(got["triPrimIdx"][nd["first"]:nd["first"] + nd["count"]].tolist())
                 cur = int(nd["skipIndex"])
             else:
