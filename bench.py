@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json configs[] index + 1 (default 2 = configs[1])")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall-time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (non-default => not the headline config)")
+    ap.add_argument("--device-tlas", action="store_true", help="after the upload rebuild the TLAS on the device (hrt_scene_update_instances, "
+                    "ForceRebuild): same picture, another tree than the reference's builder makes (not the headline setting)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,6 +153,8 @@ def main():
     s = engine.Scene()
     scenes.build(args.config, s)
     r.commit(s)
+    if args.device_tlas:
+        r.update_instances([], [], T.REBUILD_FORCE_REBUILD)
     p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction)
     strips = (world, rank)
     P = cfg.width * cfg.height
@@ -211,7 +215,7 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
             "config": {"workload": cfg.name, "description": cfg.description, "width": cfg.width, "height": cfg.height, "spp": cfg.spp,
-                       "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
+                       "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "tlas": "rebuilt on the device (LBVH)" if args.device_tlas else "as uploaded (reference builder)", "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
                        "rays_per_step": int(rays_total)},
             "roofline": {"bound": "hbm", "kernel": ("hrt_path_trace_kernel (fused)" if fused else "path-trace stage, streamed: hrt_wf_{init,shade,walk_shadow,walk_closest,finish,resolve}_kernel"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": traffic,
