@@ -153,10 +153,21 @@ def main():
     s = engine.Scene()
     scenes.build(args.config, s)
     r.commit(s)
-    if args.device_tlas:
-        r.update_instances([], [], T.REBUILD_FORCE_REBUILD)
     p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction)
     strips = (world, rank)
+    same_picture = None
+    if args.device_tlas:
+        # the frame on the uploaded tree and on the device-built one must be the same picture (they are unless two
+        # instances are hit at bit-equal distance, or the scene holds rotated / enlarged instances: DESIGN.md 4)
+        names = ["color", "depth", "objectId", "radiance"]
+        a0, o0 = T.alloc_outputs(cfg.width, cfg.height, names=names)
+        r.render_params(p, o0, strips=strips)
+        r.update_instances([], [], T.REBUILD_FORCE_REBUILD)
+        r.reset_history()
+        a1, o1 = T.alloc_outputs(cfg.width, cfg.height, names=names)
+        r.render_params(p, o1, strips=strips)
+        r.reset_history()
+        same_picture = all(a0[k].tobytes() == a1[k].tobytes() for k in names)
     P = cfg.width * cfg.height
     n_nodes = len(s.arrays()["tlasNodes"]) + len(s.arrays()["blasNodes"])
     fused = n_nodes <= 256            # the library's own choice (hrt_runtime.hip kSmallSceneNodes); reported, not forced
@@ -215,7 +226,7 @@ def main():
             "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (REHEARSAL: ranks share one GPU)" if rehearsal else ""),
             "config": {"workload": cfg.name, "description": cfg.description, "width": cfg.width, "height": cfg.height, "spp": cfg.spp,
-                       "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "tlas": "rebuilt on the device (LBVH)" if args.device_tlas else "as uploaded (reference builder)", "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
+                       "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False, "tlas": ("rebuilt on the device (LBVH); picture bit-identical to the uploaded tree's: %s" % same_picture) if args.device_tlas else "as uploaded (reference builder)", "parallelism": "row-strips x%d (8-row strips, round-robin)" % world,
                        "rays_per_step": int(rays_total)},
             "roofline": {"bound": "hbm", "kernel": ("hrt_path_trace_kernel (fused)" if fused else "path-trace stage, streamed: hrt_wf_{init,shade,walk_shadow,walk_closest,finish,resolve}_kernel"), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                          "frac": round(achieved / (HBM_PEAK_GBS * world), 5), "traffic": traffic,

@@ -384,55 +384,6 @@ __global__ void __launch_bounds__(kBlock) k_lbvh_inner(TlasDevice T, int L, int 
     if (j == 0) T.parInt[0] = -1;
 }
 
-// walk-order index of every node: the path from the root adds 1 per left edge and 1 + size(left subtree) per right edge;
-// a subtree over n leaves has 2n - 1 nodes.  node < L - 1: inner node; else leaf node - (L - 1).
-__global__ void __launch_bounds__(kBlock) k_lbvh_index(TlasDevice T, int L)
-{
-    const int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= 2 * L - 1) return;
-    const bool leaf = v >= L - 1;
-    int start = leaf ? v - (L - 1) : T.rngA[v];
-    int p = leaf ? T.parLeaf[v - (L - 1)] : T.parInt[v];
-    int idx = 0;
-    while (p >= 0)
-    {
-        const int g = T.split[p], a = T.rngA[p];
-        idx += start == g + 1 ? 2 * (g - a + 1) : 1;
-        start = a;
-        p = T.parInt[p];
-    }
-    if (leaf) T.idxLeaf[v - (L - 1)] = idx; else T.idxInt[v] = idx;
-}
-
-__global__ void __launch_bounds__(kBlock) k_lbvh_emit(TlasDevice T, int L)
-{
-    const int v = blockIdx.x * kBlock + threadIdx.x;
-    const int total = 2 * L - 1;
-    if (v >= total) return;
-    const bool leaf = v >= L - 1;
-    const int k = v - (L - 1);
-    const int idx = leaf ? T.idxLeaf[k] : T.idxInt[v];
-    const int leaves = leaf ? 1 : T.rngB[v] - T.rngA[v] + 1;
-    int skip = idx + 2 * leaves - 1;
-    if (skip >= total) skip = kEnd;
-    const int p = leaf ? T.parLeaf[k] : T.parInt[v];
-    T.parent[idx] = p < 0 ? -1 : T.idxInt[p];
-    NodeQ* q = T.tlas + idx;
-    if (leaf)
-    {
-        const int cnt = min(2, T.nI - 2 * k);
-        q->lo.w = i2f(2 * k);
-        q->hi.w = i2f(skip | (int)((unsigned)cnt << 28));
-        T.nchild[idx] = 0;
-    }
-    else
-    {
-        q->lo.w = i2f(idx + 1);
-        q->hi.w = i2f(skip);
-        T.nchild[idx] = 2;
-    }
-}
-
 __global__ void k_single_leaf(TlasDevice T)
 {   // <= 2 instances: the root is the only node
     T.tlas[0].lo.w = i2f(0);
@@ -625,6 +576,46 @@ __global__ void __launch_bounds__(kBlock) k_blas_tail(TlasDevice T, BlasDevice B
     r->left = -1; r->right = -1; r->first = -1; r->count = 0; r->skipIndex = -1;
 }
 
+// the same emission for the TLAS (items = instances, leaf-size limit 2 like the reference's TLAS, Scene.cs:469-510)
+__global__ void __launch_bounds__(kBlock) k_tlas_emit(TlasDevice T, int limit)
+{
+    const int n = T.nI;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= 2 * n - 1) return;
+    const int size = knode_size(T, n, v);
+    const int p = knode_parent(T, n, v);
+    const bool leaf = size <= limit;
+    if (leaf && p >= 0 && knode_size(T, n, p) <= limit) return;
+    const int a = knode_first(T, n, v), b = a + size - 1;
+    const int* S = T.lsum;
+    int idx = 0, start = a, parentDelta = 0;
+    for (int q = p; q >= 0; q = T.parInt[q])
+    {
+        const int g = T.split[q], qa = T.rngA[q];
+        const int d = start == g + 1 ? 2 * (S[g + 1] - S[qa]) : 1;
+        if (q == p) parentDelta = d;
+        idx += d;
+        start = qa;
+    }
+    const int total = 2 * S[n] - 1;
+    const int emitted = 2 * (S[b + 1] - S[a]) - 1;
+    T.parent[idx] = p < 0 ? -1 : idx - parentDelta;
+    const int skip = idx + emitted >= total ? kEnd : idx + emitted;
+    NodeQ* q = T.tlas + idx;
+    if (leaf)
+    {
+        q->lo.w = i2f(a);
+        q->hi.w = i2f(skip | (int)((unsigned)size << 28));
+        T.nchild[idx] = 0;
+    }
+    else
+    {
+        q->lo.w = i2f(idx + 1);
+        q->hi.w = i2f(skip);
+        T.nchild[idx] = 2;
+    }
+}
+
 // every lane of the FTri records of a rebuilt leaf region (the FTri half of validate_and_pack)
 __global__ void __launch_bounds__(kBlock) k_tri_records_full(BlasDevice B, int first, int n)
 {
@@ -737,16 +728,16 @@ hipError_t tlas_set_transforms(const TlasDevice& T, const int32_t* idsDev, const
     return hipGetLastError();
 }
 
-hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s)
+hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s, int* leavesOut)
 {
     const int n = T.nI;
     if (n <= 0) return hipErrorInvalidValue;
-    const int L = (n + 1) / 2;
     T.nTI = n;
-    T.nT = 2 * L - 1;
-    if (T.nT > T.capT || T.nTI > T.capTI) return hipErrorInvalidValue;
-    if (L == 1)
+    if (n > T.capTI) return hipErrorInvalidValue;
+    if (n <= 2)
     {
+        T.nT = 1;
+        if (leavesOut) *leavesOut = 1;
         k_single_leaf<<<1, 1, 0, s>>>(T);
         return hipGetLastError();
     }
@@ -760,9 +751,19 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s)
     size_t bytes = T.sortTmpBytes;
     e = hipcub::DeviceRadixSort::SortPairs(T.sortTmp, bytes, (const unsigned*)T.keys, T.keysSorted, (const int*)T.vals, (int*)T.tlasInst, n, 0, 30, s);
     if (e != hipSuccess) return e;
-    k_lbvh_inner<<<blocks_for(L - 1), kBlock, 0, s>>>(T, L, 2);
-    k_lbvh_index<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
-    k_lbvh_emit<<<blocks_for(2 * L - 1), kBlock, 0, s>>>(T, L);
+    // Karras over the single instances; subtrees of <= 2 instances become the leaves (see the BLAS rebuild)
+    k_lbvh_inner<<<blocks_for(n - 1), kBlock, 0, s>>>(T, n, 1);
+    if ((e = hipMemsetAsync(T.lstart, 0, (size_t)(n + 1) * sizeof(int), s)) != hipSuccess) return e;
+    k_mark_leaves<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n, 2);
+    bytes = T.iscanTmpBytes;
+    if ((e = hipcub::DeviceScan::ExclusiveSum(T.iscanTmp, bytes, (const int*)T.lstart, T.lsum, n + 1, s)) != hipSuccess) return e;
+    int leaves = 0;
+    if ((e = hipMemcpyAsync(&leaves, T.lsum + n, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    T.nT = 2 * leaves - 1;
+    if (leaves < 1 || T.nT > T.capT) return hipErrorInvalidValue;
+    if (leavesOut) *leavesOut = leaves;
+    k_tlas_emit<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, 2);
     return hipGetLastError();
 }
 

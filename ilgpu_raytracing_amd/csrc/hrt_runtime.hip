@@ -1291,7 +1291,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->n_positions = s->n_meshPositions;
     for (int i = 0; i < 15; i++) c->scene_count[i] = cnt[i];
     // room for a TLAS rebuilt on the device over all instances (leaves of two: hrt_bvh.hpp)
-    const int64_t capT = std::max<int64_t>(std::max<int64_t>(s->n_tlasNodes, 2 * ((s->n_instances + 1) / 2) - 1), 1);
+    const int64_t capT = std::max<int64_t>(std::max<int64_t>(s->n_tlasNodes, 2 * s->n_instances - 1), 1);
     const int64_t capTI = std::max<int64_t>(std::max<int64_t>(s->n_tlasInstanceIndices, s->n_instances), 1);
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
@@ -1392,16 +1392,16 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
     if (d.tlscratch) return HRT_OK;
     TlasDevice& T = d.tl;
     const size_t n = (size_t)std::max(std::max(T.nI, c->max_mesh_items), 1);
-    const size_t L = std::max<size_t>(((size_t)std::max(T.nI, 1) + 1) / 2, (size_t)c->max_mesh_items) + 1;      // TLAS: leaves of two; BLAS: Karras over single triangles
-    const size_t sortBytes = tlas_sort_temp_bytes((int)n), iscanBytes = tlas_iscan_temp_bytes((int)c->max_mesh_items + 1);
+    const size_t L = n + 1;                                                                                   // Karras' tree over the single items
+    const size_t sortBytes = tlas_sort_temp_bytes((int)n), iscanBytes = tlas_iscan_temp_bytes((int)n + 1);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t total = 3 * up(n * 4) + 7 * up(L * 4) + up(6 * 4) + up(sortBytes) + 2 * up((n + 1) * 4) + up(16 * 4) + up(iscanBytes);
+    const size_t total = 3 * up(n * 4) + 5 * up(L * 4) + up(6 * 4) + up(sortBytes) + 2 * up((n + 1) * 4) + up(16 * 4) + up(iscanBytes);
     HIPCHK(c, hipMalloc(&d.tlscratch, total));
     char* p = (char*)d.tlscratch;
     auto take = [&](size_t b) { char* r = p; p += up(b); return (void*)r; };
     T.keys = (unsigned*)take(n * 4); T.keysSorted = (unsigned*)take(n * 4); T.vals = (int*)take(n * 4);
     T.rngA = (int*)take(L * 4); T.rngB = (int*)take(L * 4); T.split = (int*)take(L * 4); T.parInt = (int*)take(L * 4);
-    T.parLeaf = (int*)take(L * 4); T.idxInt = (int*)take(L * 4); T.idxLeaf = (int*)take(L * 4);
+    T.parLeaf = (int*)take(L * 4);
     T.cboundsKey = (unsigned*)take(6 * 4);
     T.lstart = (int*)take((n + 1) * 4); T.lsum = (int*)take((n + 1) * 4); T.leafCounts = (int*)take(16 * 4);
     T.iscanTmp = take(iscanBytes); T.iscanTmpBytes = iscanBytes;
@@ -1460,6 +1460,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         if ((rc = mutate(d, staged)) != HRT_OK) return rc;
         int action = policy == HRT_REBUILD_FORCE_REBUILD ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT;
         float growthRefit = 0.f;
+        int rebuiltLeaves = 0;
         if (action == HRT_REBUILD_FORCE_REFIT)
         {
             if ((rc = finish_and_read()) != HRT_OK) return rc;
@@ -1469,7 +1470,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         if (action == HRT_REBUILD_FORCE_REBUILD)
         {
             if ((rc = ensure_lbvh_scratch(c, d)) != HRT_OK) return rc;
-            HIPCHK(c, tlas_rebuild_topology(T, d.stream));
+            HIPCHK(c, tlas_rebuild_topology(T, d.stream, &rebuiltLeaves));
             T.directMax = 63;                                           // emitted in walk order
             if ((rc = finish_and_read()) != HRT_OK) return rc;
             if ((rc = keep_as_base()) != HRT_OK) return rc;
@@ -1492,7 +1493,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
             out.action = action; out.tlas_nodes = T.nT; out.tlas_slots = T.nTI; out.general_instances = general ? 1 : 0;
             out.growth_refit = growthRefit; out.growth_final = h_cost[0]; out.sah_cost = h_cost[1]; out.device_ms = ms;
-            if (action == HRT_REBUILD_FORCE_REBUILD) { c->tlas_leaves = (T.nI + 1) / 2; c->refit_ok = true; }
+            if (action == HRT_REBUILD_FORCE_REBUILD) { c->tlas_leaves = rebuiltLeaves; c->refit_ok = true; }
             c->packed_feat = c->feat_alpha ? 3 : (general ? 1 : 0);
             c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
             c->n_tlas = T.nT; c->n_slots = T.nTI;

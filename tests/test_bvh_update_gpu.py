@@ -143,11 +143,11 @@ def _check_frames(orc, r, desc, cfg, w, h, spp):
 def _check_valid_tlas(nodes, idx, inst):
     n_inst = len(inst)
     assert sorted(idx.tolist()) == list(range(n_inst)), "every instance in exactly one leaf slot"
-    leaves = (n_inst + 1) // 2
-    assert len(nodes) == 2 * leaves - 1
     walk = _walk(nodes, idx)
     assert len(walk) == len(nodes), "every node is on the walk"
-    assert all(len(l) <= 2 for _, _, l in walk if l is not None)
+    leaves = sum(1 for _, _, l in walk if l is not None)
+    assert len(nodes) == 2 * leaves - 1 and (n_inst + 1) // 2 <= leaves <= n_inst
+    assert all(1 <= len(l) <= 2 for _, _, l in walk if l is not None)
     assert sum(len(l) for _, _, l in walk if l is not None) == n_inst
     again = _refit_numpy(nodes, idx, inst)
     assert nodes.tobytes() == again.tobytes(), "every box is the union of what it holds"
@@ -321,7 +321,7 @@ def test_big_tree_refit_and_rebuild(orc, renderer):
     # rebuild
     st = renderer.update_instances([], [], T.REBUILD_FORCE_REBUILD)
     nodes, idx, inst = _download(renderer)
-    assert sorted(idx.tolist()) == list(range(n + 1)) and len(nodes) == 2 * ((n + 2) // 2) - 1 == st.tlas_nodes
+    assert sorted(idx.tolist()) == list(range(n + 1)) and len(nodes) == st.tlas_nodes and len(nodes) % 2 == 1
     assert len(_walk(nodes, idx)) == len(nodes)
     assert nodes.tobytes() == _refit_numpy_fast(nodes, idx, inst).tobytes()
     cfg, w, h, spp = scenes.CONFIGS[3], 160, 96, 1
