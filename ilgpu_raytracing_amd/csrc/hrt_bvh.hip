@@ -7,6 +7,7 @@
 #include "hrt_bvh.hpp"
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
+#include <cstdlib>
 
 namespace hrt {
 namespace {
@@ -754,7 +755,9 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s, int* leavesOut)
     // Karras over the single instances; subtrees of <= 2 instances become the leaves (see the BLAS rebuild)
     k_lbvh_inner<<<blocks_for(n - 1), kBlock, 0, s>>>(T, n, 1);
     if ((e = hipMemsetAsync(T.lstart, 0, (size_t)(n + 1) * sizeof(int), s)) != hipSuccess) return e;
-    k_mark_leaves<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n, 2);
+    int limit = 2;                                   // the reference's TLAS leaf size; HRT_TLAS_LEAF_LIMIT = 1..14 for experiments
+    if (const char* e2 = getenv("HRT_TLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 1 && v <= 14) limit = v; }
+    k_mark_leaves<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n, limit);
     bytes = T.iscanTmpBytes;
     if ((e = hipcub::DeviceScan::ExclusiveSum(T.iscanTmp, bytes, (const int*)T.lstart, T.lsum, n + 1, s)) != hipSuccess) return e;
     int leaves = 0;
@@ -763,7 +766,7 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s, int* leavesOut)
     T.nT = 2 * leaves - 1;
     if (leaves < 1 || T.nT > T.capT) return hipErrorInvalidValue;
     if (leavesOut) *leavesOut = leaves;
-    k_tlas_emit<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, 2);
+    k_tlas_emit<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, limit);
     return hipGetLastError();
 }
 
