@@ -1,9 +1,10 @@
-// hrt_bvh.hip -- kernels behind hrt_scene_update_instances (see hrt_bvh.hpp for what they replace in the reference).
+// hrt_bvh.hip -- kernels behind hrt_scene_update_instances and hrt_scene_update_positions (see hrt_bvh.hpp for what they
+// replace in the reference).
 //
-// All of it is small integer / min-max work over arrays of a few bytes per instance: one thread per instance, leaf
-// slot or node, coalesced where the numbering allows, no LDS tiling.  The only ordering problems are the bottom-up
-// box pass (solved with one arrival counter per inner node, release/acquire at agent scope) and the sort of the
-// Morton keys (hipCUB radix sort, stable, so equal keys keep instance order and the tree is deterministic).
+// All of it is small integer / min-max work over arrays of a few bytes per instance, triangle or node: one thread per item,
+// coalesced where the numbering allows, no LDS tiling.  The only ordering problems are the bottom-up box pass (small
+// subtrees straight from their leaves, one arrival counter per inner node above them, release/acquire at agent scope) and
+// the sort of the Morton keys (hipCUB radix sort, stable, so equal keys keep item order and the trees are deterministic).
 #include "hrt_bvh.hpp"
 #include <hipcub/hipcub.hpp>
 #include <cfloat>
