@@ -495,5 +495,62 @@ class RTRenderer:
         return out
 
 
+# ------------------------------------------------------------------ SceneManager / BvhManager (Engine/SceneManager.cs, BvhManager.cs)
+class SceneManager:
+    """SceneManager (SceneManager.cs:12-38) over one RTRenderer: Scene, BuildDefaultScene, LoadObjInstance, Commit(policy),
+    ReplaceScene.  Commit is BvhManager.BuildOrRefit (BvhManager.cs:27) with the RebuildPolicy honoured: the first commit, and
+    any commit after the scene's structure changed (instances, spheres, meshes added), uploads everything as the reference
+    does; a commit after only instance transforms moved (set_instance_transform) updates the device copy in place."""
+
+    def __init__(self, renderer, existing_scene=None):
+        if renderer is None:
+            raise ValueError("renderer is None")                    # ArgumentNullException(nameof(cuda))
+        self._r = renderer
+        self._scene = existing_scene if existing_scene is not None else Scene()
+        self._uploaded_shape = None
+        self._moved = {}
+        self.last_update = None
+
+    @property
+    def scene(self):
+        return self._scene
+
+    def build_default_scene(self):
+        self._scene.build_default_scene()
+
+    def load_obj_instance(self, obj_path, object_to_world=None, uniform_scale=1.0):
+        return self._scene.load_obj_instance(obj_path, object_to_world, uniform_scale)
+
+    def set_instance_transform(self, inst_id, object_to_world):
+        """Moves an instance of the scene; takes effect at the next commit."""
+        self._scene.set_instance_transform(inst_id, object_to_world)
+        self._moved[int(inst_id)] = object_to_world
+
+    def _shape(self):
+        d = self._scene.desc()
+        return tuple(getattr(d, "n_" + n) for n, _ in T.SCENE_ARRAYS)
+
+    def commit(self, policy=T.REBUILD_AUTO):
+        shape = self._shape()
+        if self._uploaded_shape != shape:
+            self._scene.rebuild_tlas()                                # a host that added or moved things before its first commit
+            self._r.commit(self._scene)
+            self._uploaded_shape = self._shape()
+            self.last_update = None
+        elif self._moved:
+            ids = sorted(self._moved)
+            self.last_update = self._r.update_instances(ids, [self._moved[i] for i in ids], policy)
+        self._moved = {}
+
+    def replace_scene(self, new_scene, rebuild_immediately=True, policy=T.REBUILD_AUTO):
+        if new_scene is None:
+            raise ValueError("new_scene is None")
+        self._scene = new_scene
+        self._uploaded_shape = None
+        self._moved = {}
+        if rebuild_immediately:
+            self.commit(policy)
+
+
 def device_count():
     return lib().hrt_device_count()

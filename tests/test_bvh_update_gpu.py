@@ -489,3 +489,35 @@ def test_deformed_meshes_get_a_new_blas_on_the_device(orc, renderer, name):
     assert renderer.download_array("triPrimIdx").tobytes() == got["triPrimIdx"].tobytes()
     renderer.update_positions(0, new[:0], T.REBUILD_FORCE_REFIT)
     assert renderer.download_array("blasNodes").tobytes() == got["blasNodes"].tobytes()
+
+
+def test_scene_manager_commit_honours_the_policy(orc, renderer):
+    """SceneManager.Commit(policy) (SceneManager.cs:23 -> BvhManager.BuildOrRefit): full upload when the structure changed,
+    in-place update of the device copy when only instances moved."""
+    cfg, w, h, spp = scenes.Config("sm", 0, 0, 0, (0.0, 1.4, 4.5), (0.0, 0.5, 0.0)), 128, 80, 2
+    m = engine.SceneManager(renderer)
+    m.build_default_scene()
+    m.commit()
+    assert m.last_update is None
+    so = orc.OrcScene(); so.build_default_scene()
+    _check_frames(orc, renderer, so.desc(), cfg, w, h, spp)
+    move = scenes.rotation_affine("y", 0.0, 1.0, (0.4, 0.3, -0.6))
+    m.set_instance_transform(2, move)
+    m.commit(T.REBUILD_FORCE_REFIT)
+    assert m.last_update is not None and m.last_update.action == T.REBUILD_FORCE_REFIT and m.last_update.general_instances == 1
+    so.set_instance_transform(2, move)
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == so.arrays()["instances"].tobytes() == m.scene.arrays()["instances"].tobytes()
+    _check_frames(orc, renderer, _desc_with_tlas(so.desc(), nodes, idx, inst), cfg, w, h, spp)
+    m.commit(T.REBUILD_FORCE_REBUILD)                       # nothing moved, nothing added: nothing to do
+    assert renderer.download_tlas()[3][0] == len(nodes)
+    # a new instance changes the structure: everything is rebuilt on the host and uploaded, as the reference always does
+    sid = m.scene.add_sphere(scenes.sphere((0.3, 1.6, 0.2), 0.3, (0.9, 0.6, 0.1)))
+    m.scene.build_sphere_instance([sid])
+    m.commit()
+    assert m.last_update is None
+    sid2 = so.add_sphere(scenes.sphere((0.3, 1.6, 0.2), 0.3, (0.9, 0.6, 0.1)))
+    so.build_sphere_instance([sid2]); so.rebuild_tlas()
+    _check_frames(orc, renderer, so.desc(), cfg, w, h, spp)
+    with pytest.raises(ValueError):
+        engine.SceneManager(None)
