@@ -217,7 +217,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "r01_traffic_config%d.json" % args.config)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch") if tj.get("spp") in (None, cfg.spp) else None      # measured at this sample count only
             except Exception:
                 traffic = None
         out = {

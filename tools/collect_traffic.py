@@ -13,6 +13,7 @@ ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--out", default=None)
 ap.add_argument("--dir", default="gpurun_out/traffic")
 ap.add_argument("--fetch-factor", type=float, default=1.0)
+ap.add_argument("--spp", type=int, default=0, help="bench.py --spp override (0: the config's own)")
 args = ap.parse_args()
 # MI355X_MICROARCH.md: FETCH_SIZE under-reports wide (16 B/lane) coalesced streams by 2x on gfx950 and is
 # "uncalibrated for other widths: calibrate on a known byte count in your own access pattern".  These kernels read
@@ -25,7 +26,7 @@ res = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(args.dir, "c%d_%s" % (args.config, ctr))
     cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config", str(args.config)]
+           sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--config", str(args.config)] + (["--spp", str(args.spp)] if args.spp else [])
     subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=600)
     per_kernel = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -36,7 +37,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             per_kernel[k.split("(")[0].replace("void ", "")].append(float(row["Counter_Value"]))
     res[ctr] = per_kernel
 frames = max(1, len([v for k, vs in res["FETCH_SIZE"].items() if "primary" in k for v in vs]))
-out = {"config": args.config, "frames": frames, "kernels": {}}
+out = {"config": args.config, "spp": args.spp or None, "frames": frames, "kernels": {}}
 tot_path = 0.0
 for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
     f = sum(res["FETCH_SIZE"].get(k, [])) / frames * 1024.0 * FETCH_FACTOR
