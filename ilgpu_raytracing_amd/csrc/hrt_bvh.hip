@@ -7,6 +7,7 @@
 // the sort of the Morton keys (hipCUB radix sort, stable, so equal keys keep item order and the trees are deterministic).
 #include "hrt_bvh.hpp"
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -121,10 +122,11 @@ __global__ void __launch_bounds__(kBlock) k_leaf_slots(TlasDevice T)
 // One thread per node.  In walk-order numbering the subtree of node i is the index range [i, skip(i)), so a node whose
 // subtree has at most T.directMax nodes takes its box straight from the instances of the leaves in that range
 // (BuildTLASNodeRecursive's own loop over its items, Scene.cs:472-480) -- no ordering between threads at all for the
-// bottom five levels, which hold 31 of every 32 nodes.  Above that the boxes are united bottom-up: a finished node
-// reports to its parent, and the last child to arrive unites the children (the chain left, left.skip, ... up to the
-// parent's own skip link) and climbs on.  Release / acquire at agent scope costs an L2 write-back per step on a
-// multi-XCD part, which is why only one node in 32 takes part.  min / max are exact: no order can change a bit.
+// bottom five levels, which hold 31 of every 32 nodes; k_refit_level finishes the rest.  Only a tree that is not numbered
+// in walk order (HRT_BUILDER_ORDER) climbs: leaves report to their parent through one arrival counter, the last child to
+// arrive unites the children (the chain left, left.skip, ... up to the parent's own skip link) and climbs on; release /
+// acquire at agent scope costs an L2 write-back per step on a multi-XCD part (300 us for a 131 k-node tree when every
+// node climbed).  min / max are exact: no order can change a bit.
 HRT_D int subtree_size(const TlasDevice& T, int i)
 {
     const int sk = node_skip(T.tlas, i);
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
     {
         const int p = T.parent[cur];
         if (p < 0) break;
-        if (cur == i && T.directMax > 1 && subtree_size(T, p) <= T.directMax) break;     // the parent computes its own box
+        if (T.directMax > 1) break;                            // walk-order tree: k_refit_level takes over above the direct subtrees
         const int old = __hip_atomic_fetch_add(T.arrive + p, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1 < T.nchild[p]) break;
         const int pskip = node_skip(nodes, p);
@@ -173,6 +175,32 @@ __global__ void __launch_bounds__(kBlock) k_refit(TlasDevice T)
         nodes[p].hi.x = mx.x; nodes[p].hi.y = mx.y; nodes[p].hi.z = mx.z;
         cur = p;
     }
+}
+
+// Walk-order trees need no arrival counters at all: a node whose subtree has more than `lo` and at most `hi` nodes unites the
+// boxes of the maximal subtrees of at most `lo` nodes inside its index range (finished by the previous launch), hopping over
+// each of them with its skip link.  With lo = 63, 63 * 64, ... three or four launches reach the root of any tree, every
+// thread reads at most a few hundred boxes, and a kernel boundary is the only synchronisation.
+__global__ void __launch_bounds__(kBlock) k_refit_level(TlasDevice T, int lo, int hi)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= T.nT) return;
+    NodeQ* nodes = T.tlas;
+    if (node_cnt(nodes, i) > 0) return;
+    const int size = subtree_size(T, i);
+    if (size <= lo || size > hi) return;
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    const int end = i + size;
+    for (int j = i + 1; j < end;)
+    {
+        const float4 qlo = nodes[j].lo, qhi = nodes[j].hi;
+        const int sk = f2i(qhi.w) & kEnd;
+        const int e = sk == kEnd ? T.nT : sk;
+        if (e - j <= lo) { mn = min3(mn, mk3(qlo.x, qlo.y, qlo.z)); mx = max3(mx, mk3(qhi.x, qhi.y, qhi.z)); j = e; }
+        else j++;
+    }
+    nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
+    nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
 }
 
 // ------------------------------------------------------------------ exclusive scans over the node list
@@ -442,7 +470,7 @@ __global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
     {
         const int p = B.parent[cur];
         if (p < 0) break;
-        if (cur == i && B.subend[p] - p <= B.directMax) break;
+        if (B.directMax > 1) break;                            // k_blas_refit_level takes over above the direct subtrees
         const int old = __hip_atomic_fetch_add(B.arrive + p, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1 < B.nchild[p]) break;
         const int pskip = node_skip(nodes, p);
@@ -458,6 +486,29 @@ __global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
         nodes[p].hi.x = mx.x; nodes[p].hi.y = mx.y; nodes[p].hi.z = mx.z;
         cur = p;
     }
+}
+
+__global__ void __launch_bounds__(kBlock) k_blas_refit_level(BlasDevice B, int lo, int hi)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.nB || B.parent[i] == -2) return;
+    NodeQ* nodes = B.blas;
+    const int end = B.subend[i], size = end - i;
+    if (size <= lo || size > hi) return;
+    F3 mn = mk3(FLT_MAX, FLT_MAX, FLT_MAX), mx = mk3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int j = i + 1; j < end;)
+    {
+        const int e = B.subend[j];
+        if (e - j <= lo)
+        {
+            const float4 qlo = nodes[j].lo, qhi = nodes[j].hi;
+            mn = min3(mn, mk3(qlo.x, qlo.y, qlo.z)); mx = max3(mx, mk3(qhi.x, qhi.y, qhi.z));
+            j = e;
+        }
+        else j++;
+    }
+    nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
+    nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
 }
 
 __global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B)
@@ -698,6 +749,9 @@ hipError_t blas_refit(const BlasDevice& B, hipStream_t s)
     if ((e = hipMemsetAsync(B.arrive, 0, (size_t)B.nB * sizeof(int), s)) != hipSuccess) return e;
     if (B.nSlots > 0) k_tri_records<<<blocks_for(B.nSlots), kBlock, 0, s>>>(B);
     k_blas_refit<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
+    if (B.directMax > 1)
+        for (long long lo = B.directMax; lo < B.nB; lo *= 64)
+            k_blas_refit_level<<<blocks_for(B.nB), kBlock, 0, s>>>(B, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
     k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
     return hipGetLastError();
 }
@@ -778,6 +832,9 @@ hipError_t tlas_finish(const TlasDevice& T, hipStream_t s)
     if ((e = hipMemsetAsync(T.arrive, 0, (size_t)T.nT * sizeof(int), s)) != hipSuccess) return e;
     if (T.nTI > 0) k_leaf_slots<<<blocks_for(T.nTI), kBlock, 0, s>>>(T);
     k_refit<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
+    if (T.directMax > 1)
+        for (long long lo = T.directMax; lo < T.nT; lo *= 64)
+            k_refit_level<<<blocks_for(T.nT), kBlock, 0, s>>>(T, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
     k_scan_input<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
     size_t bytes = T.scanTmpBytes;
     if ((e = hipcub::DeviceScan::ExclusiveSum(T.scanTmp, bytes, (const unsigned long long*)T.scanIn, T.scanOut, T.nT, s)) != hipSuccess) return e;
