@@ -521,3 +521,29 @@ def test_scene_manager_commit_honours_the_policy(orc, renderer):
     _check_frames(orc, renderer, so.desc(), cfg, w, h, spp)
     with pytest.raises(ValueError):
         engine.SceneManager(None)
+
+
+def test_refit_of_a_tree_in_builder_numbering(orc, renderer, monkeypatch):
+    """HRT_BUILDER_ORDER keeps the uploaded numbering, where a subtree is no index range: the refit then climbs with arrival
+    counters (release / acquire at agent scope) from every leaf.  2001 instances: 2357 nodes, eleven levels."""
+    monkeypatch.setenv("HRT_BUILDER_ORDER", "1")
+    n = 2000
+    s = engine.Scene(); scenes.build_random_spheres(s, n, extent=9.0); renderer.commit(s)
+    so = orc.OrcScene(); scenes.build_random_spheres(so, n, extent=9.0)
+    ids = np.arange(1, n + 1, dtype=np.int32)
+    rng = np.random.default_rng(5)
+    xf = np.zeros((n, 12), np.float32); xf[:, 0] = xf[:, 5] = xf[:, 10] = 1.0
+    xf[:, [3, 7, 11]] = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    for k in range(n):
+        m = T.identity_affine(); m.m03, m.m13, m.m23 = float(xf[k, 3]), float(xf[k, 7]), float(xf[k, 11])
+        so.set_instance_transform(int(ids[k]), m)
+    st = renderer.update_instances(ids, xf, T.REBUILD_FORCE_REFIT)
+    assert st.action == T.REBUILD_FORCE_REFIT
+    oa = so.arrays()
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == oa["instances"].tobytes()
+    import sys
+    sys.setrecursionlimit(10000)
+    assert _walk(nodes, idx) == _walk(_refit_numpy(oa["tlasNodes"], oa["tlasInstanceIndices"], oa["instances"]), oa["tlasInstanceIndices"])
+    monkeypatch.delenv("HRT_BUILDER_ORDER")
+    s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # leave the shared renderer in its default state
