@@ -88,6 +88,7 @@ namespace ILGPU_Raytracing.Engine
         public const int HRT_REBUILD_BLAS = 16;
         [DllImport(Lib)] public static extern int hrt_scene_update_instances(IntPtr ctx, int* instanceIds, int n, Affine3x4* objectToWorld, int policy, HrtBvhUpdateStats* stats);
         [DllImport(Lib)] public static extern int hrt_scene_update_positions(IntPtr ctx, long firstVertex, long n, Float3* positions, int policy, HrtBvhUpdateStats* stats);
+        [DllImport(Lib)] public static extern int hrt_scene_update_spheres(IntPtr ctx, long firstSphere, long n, Sphere* spheres, int policy, HrtBvhUpdateStats* stats);
         [DllImport(Lib)] public static extern int hrt_scene_download_array(IntPtr ctx, int dev, int array, void* dst, long cap, long* count);
         [DllImport(Lib)] public static extern int hrt_scene_download_tlas(IntPtr ctx, int dev, TLASNode* nodes, long capNodes, int* indices, long capIndices, InstanceRecord* instances, long capInstances, long* counts);
         [DllImport(Lib)] public static extern int hrt_render_frame(IntPtr ctx, HrtFrameParams* p, HrtRenderOpts* opts, HrtOutputs* outputs, HrtStats* stats);

@@ -444,10 +444,10 @@ __global__ void __launch_bounds__(kBlock) k_tri_records(BlasDevice B)
 
 // Same scheme as k_refit: subtrees of up to directMax nodes straight from their triangles (BoundsOfTriangle over the
 // node's items, Scene.cs:423-429,597-605), arrival counters above.
-__global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
+__global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B, int kind)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B.nB || B.parent[i] == -2) return;
+    if (i >= B.nB || B.kind[i] != kind) return;
     NodeQ* nodes = B.blas;
     const int size = B.subend[i] - i;
     if (size > B.directMax || size < 1) return;
@@ -458,9 +458,19 @@ __global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
         const int first = node_link(nodes, j);
         for (int k = 0; k < c; k++)
         {
-            const FTri t = B.ftri[first + k];
-            const F3 a = mk3(t.v0.x, t.v0.y, t.v0.z), b = mk3(t.v1.x, t.v1.y, t.v1.z), cc = mk3(t.v2.x, t.v2.y, t.v2.z);
-            mn = min3(mn, min3(a, min3(b, cc))); mx = max3(mx, max3(a, max3(b, cc)));
+            if (kind == 1)
+            {
+                const FTri t = B.ftri[first + k];
+                const F3 a = mk3(t.v0.x, t.v0.y, t.v0.z), b = mk3(t.v1.x, t.v1.y, t.v1.z), cc = mk3(t.v2.x, t.v2.y, t.v2.z);
+                mn = min3(mn, min3(a, min3(b, cc))); mx = max3(mx, max3(a, max3(b, cc)));
+            }
+            else
+            {   // centre -+ radius per sphere of the leaf (BuildSphereInstance / BuildBLAS_Spheres, Scene.cs:331-336,386-390)
+                const hrt_sphere* sp = B.spheres + B.spherePrimIdx[first + k];
+                const float r = sp->radius;
+                mn = min3(mn, mk3(sp->center.X - r, sp->center.Y - r, sp->center.Z - r));
+                mx = max3(mx, mk3(sp->center.X + r, sp->center.Y + r, sp->center.Z + r));
+            }
         }
     }
     nodes[i].lo.x = mn.x; nodes[i].lo.y = mn.y; nodes[i].lo.z = mn.z;
@@ -488,10 +498,10 @@ __global__ void __launch_bounds__(kBlock) k_blas_refit(BlasDevice B)
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_blas_refit_level(BlasDevice B, int lo, int hi)
+__global__ void __launch_bounds__(kBlock) k_blas_refit_level(BlasDevice B, int kind, int lo, int hi)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B.nB || B.parent[i] == -2) return;
+    if (i >= B.nB || B.kind[i] != kind) return;
     NodeQ* nodes = B.blas;
     const int end = B.subend[i], size = end - i;
     if (size <= lo || size > hi) return;
@@ -511,10 +521,10 @@ __global__ void __launch_bounds__(kBlock) k_blas_refit_level(BlasDevice B, int l
     nodes[i].hi.x = mx.x; nodes[i].hi.y = mx.y; nodes[i].hi.z = mx.z;
 }
 
-__global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B)
+__global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B, int kind)
 {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B.nB || B.parent[i] == -2) return;
+    if (i >= B.nB || B.kind[i] != kind) return;
     const NodeQ q = B.blas[i];
     hrt_bvh_node* r = B.blasNodes + B.orig[i];
     r->boundsMin.X = q.lo.x; r->boundsMin.Y = q.lo.y; r->boundsMin.Z = q.lo.z;
@@ -597,6 +607,7 @@ __global__ void __launch_bounds__(kBlock) k_blas_emit(TlasDevice T, BlasDevice B
     B.parent[g] = p < 0 ? -1 : g - parentDelta;
     B.subend[g] = g + emitted;
     B.orig[g] = g;
+    B.kind[g] = 1;
     const int skip = idx + emitted >= total ? kEnd : g + emitted;
     NodeQ* q = B.blas + g;
     if (leaf)
@@ -621,7 +632,7 @@ __global__ void __launch_bounds__(kBlock) k_blas_tail(TlasDevice T, BlasDevice B
     const int v = total + blockIdx.x * kBlock + threadIdx.x;
     if (v >= J.nodeCap) return;
     const int g = J.root + v;
-    B.parent[g] = -2; B.nchild[g] = 0; B.subend[g] = g + 1; B.orig[g] = g;
+    B.parent[g] = -2; B.nchild[g] = 0; B.subend[g] = g + 1; B.orig[g] = g; B.kind[g] = 0;
     NodeQ z; z.lo = make_float4(0.f, 0.f, 0.f, i2f(kEnd)); z.hi = make_float4(0.f, 0.f, 0.f, i2f(kEnd));
     B.blas[g] = z;
     hrt_bvh_node* r = B.blasNodes + g;
@@ -743,16 +754,16 @@ hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const Mes
     return hipGetLastError();
 }
 
-hipError_t blas_refit(const BlasDevice& B, hipStream_t s)
+hipError_t blas_refit(const BlasDevice& B, int kind, hipStream_t s)
 {
     hipError_t e;
     if ((e = hipMemsetAsync(B.arrive, 0, (size_t)B.nB * sizeof(int), s)) != hipSuccess) return e;
-    if (B.nSlots > 0) k_tri_records<<<blocks_for(B.nSlots), kBlock, 0, s>>>(B);
-    k_blas_refit<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
+    if (kind == 1 && B.nSlots > 0) k_tri_records<<<blocks_for(B.nSlots), kBlock, 0, s>>>(B);
+    k_blas_refit<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
     if (B.directMax > 1)
         for (long long lo = B.directMax; lo < B.nB; lo *= 64)
-            k_blas_refit_level<<<blocks_for(B.nB), kBlock, 0, s>>>(B, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
-    k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B);
+            k_blas_refit_level<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
+    k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
     return hipGetLastError();
 }
 

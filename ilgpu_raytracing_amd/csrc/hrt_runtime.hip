@@ -297,8 +297,8 @@ struct DeviceState {
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
-    void* blaux[6] = {};                       // parent, nchild, subend, orig, arrive, ids of the TriMesh instances
-    int n_mesh_inst = 0;
+    void* blaux[8] = {};                       // parent, nchild, subend, orig, arrive, ids of the TriMesh instances, kind, ids of the SphereSet instances
+    int n_mesh_inst = 0, n_sphere_inst = 0;
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
@@ -339,7 +339,7 @@ struct hrt_ctx {
     bool blas_rebuild_ok = false;              // ... and rebuild it (HRT_REBUILD_BLAS)
     std::vector<MeshJob> mesh_jobs;
     int max_mesh_items = 0;
-    int64_t n_positions = 0;
+    int64_t n_positions = 0, n_spheres = 0;
     int64_t scene_count[15] = {};
     int width = 0, height = 0;
 };
@@ -449,8 +449,8 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
-    for (int i = 0; i < 6; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
-    d.bl = BlasDevice{}; d.n_mesh_inst = 0;
+    for (int i = 0; i < 8; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
+    d.bl = BlasDevice{}; d.n_mesh_inst = 0; d.n_sphere_inst = 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -472,6 +472,8 @@ struct PackedHost {
     std::vector<int32_t> parent, nchild;     // TLAS, packed numbering: parent of a node (-1: none), children of an inner node
     std::vector<int32_t> bparent, bnchild, bsubend, borig;   // BLAS nodes of triangle meshes, packed numbering: parent (-1 root, -2 not maintained),
                                                              // children, end of the subtree's index range, index in the uploaded numbering
+    std::vector<int32_t> bkind;                              // 0: node of no maintained BLAS, 1: triangle mesh, 2: sphere set
+    std::vector<int32_t> sphereInst;                         // ids of the SphereSet instances whose BLAS is maintained
     std::vector<int32_t> meshInst;                           // ids of the TriMesh instances whose BLAS is maintained
     std::vector<MeshJob> meshJobs;                           // the same, with what a device-side rebuild of the BLAS needs
     bool blas_rebuild_ok = true;                             // every mesh's leaves list their triangles in one region of triPrimIdx
@@ -644,7 +646,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         bool disjoint = true;
         for (size_t i = 1; i < ranges.size(); i++) if (ranges[i].first < ranges[i - 1].second) disjoint = false;
         const size_t nBq = out.blas.size();
-        out.bparent.assign(nBq, -2); out.bnchild.assign(nBq, 0); out.bsubend.assign(nBq, 0); out.borig.assign(nBq, 0);
+        out.bparent.assign(nBq, -2); out.bnchild.assign(nBq, 0); out.bsubend.assign(nBq, 0); out.borig.assign(nBq, 0); out.bkind.assign(nBq, 0);
         for (size_t j = 0; j < nBq; j++) out.borig[j] = (int32_t)j;
         if (!disjoint)
         {
@@ -662,7 +664,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
                 const hrt_instance& in = s->instances[i];
                 if (in.blasNodeCount <= 0) continue;
                 const auto it = std::lower_bound(ranges.begin(), ranges.end(), std::make_pair((int64_t)in.blasRoot, (int64_t)in.blasRoot + in.blasNodeCount));
-                rangeKind[(size_t)(it - ranges.begin())] |= in.type == HRT_BLAS_TRIMESH ? 1 : 2;
+                rangeKind[(size_t)(it - ranges.begin())] |= in.type == HRT_BLAS_TRIMESH ? 1 : (in.type == HRT_BLAS_SPHERESET ? 2 : 4);
             }
             int64_t at = 0;
             for (const auto& r : ranges)
@@ -673,9 +675,9 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
                 at = r.second;
                 // maintenance arrays for the BLAS of a triangle mesh (device refit after a vertex update, hrt_bvh.hpp)
                 const uint8_t kind = rangeKind[(size_t)(&r - ranges.data())];
-                const bool mesh = (kind & 1) != 0, other = (kind & 2) != 0;
-                if (!mesh) continue;
-                if (other || reach != (int32_t)(r.second - r.first)) { out.blas_refit_ok = false; continue; }   // shared with a sphere set, unreachable nodes or builder numbering
+                if (kind != 1 && kind != 2) { if (kind != 0) out.blas_refit_ok = false; continue; }               // shared between a mesh and a sphere set, or of an unknown type
+                if (reach != (int32_t)(r.second - r.first)) { out.blas_refit_ok = false; continue; }              // unreachable nodes or builder numbering
+                for (int64_t k = r.first; k < r.second; k++) out.bkind[(size_t)k] = kind;
                 auto cntq = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.blas[(size_t)i].hi.w) >> 28); };
                 auto skipq = [&](int64_t i) { return __builtin_bit_cast(int, out.blas[(size_t)i].hi.w) & kEnd; };
                 for (int64_t k = r.first; k < r.second; k++) out.borig[(size_t)(r.first + perm[(size_t)(k - r.first)])] = (int32_t)k;
@@ -700,6 +702,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         for (int64_t i = 0; i < nI; i++)
         {
             const hrt_instance& in = s->instances[i];
+            if (in.type == HRT_BLAS_SPHERESET && in.blasNodeCount > 0) out.sphereInst.push_back((int32_t)i);
             if (in.type != HRT_BLAS_TRIMESH || in.blasNodeCount <= 0) continue;
             out.meshInst.push_back((int32_t)i);
             // region of triPrimIdx the leaves of this BLAS point into (the builder appends it behind the item list, Scene.cs:439-440)
@@ -1288,7 +1291,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->mesh_jobs = ph.meshJobs;
     c->max_mesh_items = 0;
     for (const MeshJob& J : ph.meshJobs) c->max_mesh_items = std::max(c->max_mesh_items, J.n);
-    c->n_positions = s->n_meshPositions;
+    c->n_positions = s->n_meshPositions; c->n_spheres = s->n_spheres;
     for (int i = 0; i < 15; i++) c->scene_count[i] = cnt[i];
     // room for a TLAS rebuilt on the device over all instances (leaves of two: hrt_bvh.hpp)
     const int64_t capT = std::max<int64_t>(std::max<int64_t>(s->n_tlasNodes, 2 * s->n_instances - 1), 1);
@@ -1350,12 +1353,14 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             T.directMax = (ph.refit_ok && !getenv("HRT_BUILDER_ORDER")) ? 63 : 1;
             T.sa = (float*)d.tlaux[5]; T.flags = (int*)d.tlaux[6]; T.cost = (float*)d.tlaux[7]; T.saBase = (float*)d.tlaux[8];
             T.nI = (int)s->n_instances; T.nT = (int)s->n_tlasNodes; T.nTI = (int)s->n_tlasInstanceIndices;
-            if (!ph.meshInst.empty() && ph.blas_refit_ok)
+            if ((!ph.meshInst.empty() || !ph.sphereInst.empty()) && ph.blas_refit_ok)
             {
                 const size_t nBq = ph.blas.size();
-                const void* bsrc[6] = {ph.bparent.data(), ph.bnchild.data(), ph.bsubend.data(), ph.borig.data(), nullptr, ph.meshInst.data()};
-                const size_t bb[6] = {nBq * 4, nBq * 4, nBq * 4, nBq * 4, nBq * 4, ph.meshInst.size() * 4};
-                for (int i = 0; i < 6; i++)
+                static const int32_t none = 0;
+                const void* bsrc[8] = {ph.bparent.data(), ph.bnchild.data(), ph.bsubend.data(), ph.borig.data(), nullptr,
+                                       ph.meshInst.empty() ? &none : ph.meshInst.data(), ph.bkind.data(), ph.sphereInst.empty() ? &none : ph.sphereInst.data()};
+                const size_t bb[8] = {nBq * 4, nBq * 4, nBq * 4, nBq * 4, nBq * 4, std::max<size_t>(ph.meshInst.size(), 1) * 4, nBq * 4, std::max<size_t>(ph.sphereInst.size(), 1) * 4};
+                for (int i = 0; i < 8; i++)
                 {
                     HIPCHK(c, hipMalloc(&d.blaux[i], bb[i]));
                     if (bsrc[i]) HIPCHK(c, hipMemcpyAsync(d.blaux[i], bsrc[i], bb[i], hipMemcpyHostToDevice, d.stream));
@@ -1365,9 +1370,11 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
                 B.blasNodes = (hrt_bvh_node*)d.scene[3]; B.triPrimIdx = (const int32_t*)d.scene[6]; B.meshTris = (const hrt_mesh_tri*)d.scene[8];
                 B.triPrimIdxW = (int32_t*)d.scene[6]; B.triMatIndex = (const int32_t*)d.scene[11]; B.materials = (const hrt_material*)d.scene[12];
                 B.nMaterials = (int)s->n_materials; B.texLen = (int)(s->n_texInfos > 0 ? s->n_texInfos : 1);
+                B.spherePrimIdx = (const int32_t*)d.scene[4]; B.spheres = (const hrt_sphere*)d.scene[5]; B.kind = (int*)d.blaux[6];
                 B.positions = (hrt_float3*)d.scene[7]; B.blas = (NodeQ*)d.packed[2]; B.ftri = (FTri*)d.packed[3];
                 B.parent = (int*)d.blaux[0]; B.nchild = (int*)d.blaux[1]; B.subend = (int*)d.blaux[2]; B.orig = (int*)d.blaux[3]; B.arrive = (int*)d.blaux[4];
                 B.nB = (int)s->n_blasNodes; B.nSlots = (int)s->n_triPrimIdx; B.directMax = 63;
+                d.n_sphere_inst = (int)ph.sphereInst.size();
                 d.n_mesh_inst = (int)ph.meshInst.size();
             }
             T.capT = (int)capT; T.capTI = (int)capTI; T.flatMax = kFlatMaxLeaves;
@@ -1555,8 +1562,24 @@ int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_f
             if (rc2 != HRT_OK) return rc2;
             for (const MeshJob& J : c->mesh_jobs) HIPCHK(c, blas_rebuild_mesh(d.tl, d.bl, J, d.stream, nullptr));
         }
-        if (d.bl.nSlots > 0) HIPCHK(c, blas_refit(d.bl, d.stream));
+        if (d.n_mesh_inst > 0) HIPCHK(c, blas_refit(d.bl, 1, d.stream));
         HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[5], d.n_mesh_inst, d.stream));
+        return HRT_OK;
+    }, st);
+}
+
+int hrt_scene_update_spheres(hrt_ctx* c, int64_t first, int64_t n, const hrt_sphere* spheres, int32_t policy, hrt_bvh_update_stats* st)
+{
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_spheres: no scene uploaded");
+    if (first < 0 || n < 0 || first + n > c->n_spheres || (n > 0 && !spheres))
+        return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_spheres: range outside spheres");
+    if (!c->blas_refit_ok)
+        return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_spheres: a BLAS of this scene cannot be refitted (shared or overlapping node ranges, unreachable nodes)");
+    return apply_update(c, policy, "hrt_scene_update_spheres", [&](DeviceState& d, std::vector<void*>&) -> int {
+        if (n > 0) HIPCHK(c, hipMemcpyAsync((hrt_sphere*)d.scene[5] + first, spheres, (size_t)n * sizeof(hrt_sphere), hipMemcpyHostToDevice, d.stream));
+        if (d.n_sphere_inst > 0) HIPCHK(c, blas_refit(d.bl, 2, d.stream));
+        HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[7], d.n_sphere_inst, d.stream));
         return HRT_OK;
     }, st);
 }

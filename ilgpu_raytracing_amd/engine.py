@@ -52,6 +52,7 @@ def lib():
         L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
         L.hrt_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
         L.hrt_scene_update_positions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+        L.hrt_scene_update_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
         L.hrt_scene_download_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.hrt_scene_download_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                               C.POINTER(C.c_int64)]
@@ -381,6 +382,19 @@ class RTRenderer:
         st = T.BvhUpdateStats()
         self._check(lib().hrt_scene_update_positions(self._ctx, int(first_vertex), pos.shape[0], pos.ctypes.data if pos.size else None,
                                                      policy, C.byref(st)))
+        return st
+
+    def update_spheres(self, first_sphere, spheres, policy=T.REBUILD_AUTO):
+        """spheres[first_sphere : first_sphere + n] := spheres (a list of T.Sphere or a structured numpy array); sphere-set BLASes
+        are refitted on the device, then the TLAS per `policy` (hrt_scene_update_spheres).  Returns BvhUpdateStats."""
+        if isinstance(spheres, np.ndarray):
+            buf = np.ascontiguousarray(spheres)
+            n, ptr = len(buf), buf.ctypes.data
+        else:
+            buf = (T.Sphere * max(1, len(spheres)))(*spheres)
+            n, ptr = len(spheres), C.addressof(buf)
+        st = T.BvhUpdateStats()
+        self._check(lib().hrt_scene_update_spheres(self._ctx, int(first_sphere), n, ptr if n else None, policy, C.byref(st)))
         return st
 
     def download_array(self, name, slot=0):

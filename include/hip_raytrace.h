@@ -214,6 +214,17 @@ int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32
 int  hrt_scene_update_positions(hrt_ctx* ctx, int64_t first_vertex, int64_t n, const hrt_float3* positions,
                                 int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
 
+/* ---- moving / resizing / recolouring spheres: spheres[first, first + n) := spheres (n may be 0).  Every sphere-set BLAS
+ * keeps its topology and gets its boxes recomputed bottom-up on the device (centre -+ radius per sphere of a leaf,
+ * Scene.cs:331-336,386-390), the world bounds of the sphere-set instances are re-derived from the new root boxes, and the
+ * TLAS is refitted / rebuilt per `policy` as in hrt_scene_update_instances.  Single-sphere instances with an identity
+ * transform stay on the walkers' fast path (a moved INSTANCE would leave it: its ray transform must then be evaluated).
+ * Note: the boxes are the unions of the spheres each node really holds; the reference's own builder indexes its
+ * pre-computed bounds by array position (Scene.cs:386-395,413-419), which for more than four spheres per instance
+ * yields other (wrong) boxes on a rebuild.  Blocking; every device of the context is updated. */
+int  hrt_scene_update_spheres(hrt_ctx* ctx, int64_t first_sphere, int64_t n, const hrt_sphere* spheres,
+                              int32_t policy, hrt_bvh_update_stats* stats /* may be NULL */);
+
 /* Copies scene array `array` (0..14, in the order of hrt_scene_desc / SceneDeviceViews.cs:13-27) as it is now on device
  * slot `dev` back to the host: what TracerRef walks after updates.  *count (may be NULL) receives the element count;
  * dst may be NULL to query it; cap = capacity of dst in elements. */

@@ -547,3 +547,122 @@ def test_refit_of_a_tree_in_builder_numbering(orc, renderer, monkeypatch):
     assert _walk(nodes, idx) == _walk(_refit_numpy(oa["tlasNodes"], oa["tlasInstanceIndices"], oa["instances"]), oa["tlasInstanceIndices"])
     monkeypatch.delenv("HRT_BUILDER_ORDER")
     s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # leave the shared renderer in its default state
+
+
+# ------------------------------------------------------------------ moving spheres: hrt_scene_update_spheres
+def _refit_sphere_blas_numpy(arrs):
+    """Boxes of every sphere-set BLAS recomputed for arrs['spheres'] (topology kept: the union of centre -+ radius over the
+    spheres each node really holds), then the world bounds of those instances."""
+    nodes, inst = arrs["blasNodes"].copy(), arrs["instances"].copy()
+    sp, prim = arrs["spheres"], arrs["spherePrimIdx"]
+
+    def rec(i):
+        n = nodes[i]
+        if n["count"] > 0:
+            los, his = [], []
+            for sid in prim[n["first"]:n["first"] + n["count"]]:
+                c, r = _f3(sp[sid]["center"]), np.float32(sp[sid]["radius"])
+                los.append(c - r); his.append(c + r)
+            lo, hi = np.min(np.stack(los), axis=0), np.max(np.stack(his), axis=0)
+        else:
+            a, b = rec(int(n["left"])), rec(int(n["right"]))
+            lo, hi = np.minimum(a[0], b[0]), np.maximum(a[1], b[1])
+        for k, f in enumerate("XYZ"):
+            nodes[i]["boundsMin"][f] = lo[k]
+            nodes[i]["boundsMax"][f] = hi[k]
+        return lo, hi
+
+    for ii in range(len(inst)):
+        if inst[ii]["type"] != 1 or inst[ii]["blasNodeCount"] <= 0:
+            continue
+        lo, hi = rec(int(inst[ii]["blasRoot"]))
+        m = inst[ii]["objectToWorld"]
+        rows = [[np.float32(m["m%d%d" % (r, c)]) for c in range(4)] for r in range(3)]
+        corners = [(lo[0], lo[1], lo[2]), (hi[0], lo[1], lo[2]), (lo[0], hi[1], lo[2]), (lo[0], lo[1], hi[2]),
+                   (hi[0], hi[1], lo[2]), (lo[0], hi[1], hi[2]), (hi[0], lo[1], hi[2]), (hi[0], hi[1], hi[2])]
+        w = np.array([[((r[0] * c[0] + r[1] * c[1]) + r[2] * c[2]) + r[3] for r in rows] for c in corners], np.float32)
+        for k, f in enumerate("XYZ"):
+            inst[ii]["worldBoundsMin"][f] = w[:, k].min()
+            inst[ii]["worldBoundsMax"][f] = w[:, k].max()
+    return nodes, inst
+
+
+def _nine_in_one(b):
+    ids = [b.add_sphere(scenes.sphere((x, 0.3 * (i % 3), -0.4 * i), 0.45, (0.3 + 0.07 * i, 0.9 - 0.08 * i, 0.5)))
+           for i, x in enumerate([3.0, -2.0, 0.5, -4.0, 2.0, 1.0, -1.0, 4.0, -3.0])]
+    g = b.add_sphere(scenes.sphere((0.0, -200.0, 0.0), 199.5, (0.7, 0.7, 0.7)))
+    b.build_sphere_instance(ids)
+    b.build_sphere_instance([g])
+    b.rebuild_tlas()
+
+
+SPHERE_SCENES = {
+    "sphere_instances": SCENES["sphere_instances"],
+    "cornell_flat_leaves": SCENES["cornell_flat_leaves"],
+    "nine_spheres_in_one_blas": (_nine_in_one, scenes.Config("q", 0, 0, 0, (0.0, 1.5, 7.0), (0.0, 0.2, -1.5)), 128, 80, 2),
+    "rotated_mesh_and_sets": SCENES["rotated_mesh_and_sets"],
+}
+
+
+@pytest.mark.parametrize("policy", [T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD])
+@pytest.mark.parametrize("name", list(SPHERE_SCENES))
+def test_moved_spheres_are_refitted_on_the_device(orc, renderer, name, policy):
+    builder, cfg, w, h, spp = SPHERE_SCENES[name]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    arrs = s.arrays()
+    sp = arrs["spheres"].copy()
+    n = len(sp)
+    first, cnt = 1, n - 1                                             # sphere 0 (a ground / wall) stays
+    k = np.arange(n, dtype=np.float32)
+    sp["center"]["X"][first:] += (0.25 * np.sin(1.7 * k))[first:]
+    sp["center"]["Y"][first:] += (0.15 * np.cos(0.9 * k) + 0.1)[first:]
+    sp["center"]["Z"][first:] -= (0.2 * np.sin(0.4 * k + 1.0))[first:]
+    small = sp["radius"] < 10.0
+    small[:first] = False
+    sp["radius"][small] *= (0.8 + 0.05 * (k % 7))[small].astype(np.float32)
+    sp["albedo"]["X"][first:] = (0.2 + 0.05 * (k % 13))[first:]
+    st = renderer.update_spheres(first, sp[first:first + cnt], policy)
+    assert st.action == policy
+    arrs["spheres"] = sp
+    want_blas, want_inst = _refit_sphere_blas_numpy(arrs)
+    assert renderer.download_array("spheres").tobytes() == sp.tobytes()
+    assert renderer.download_array("blasNodes").tobytes() == want_blas.tobytes()
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == want_inst.tobytes()
+    if name in ("sphere_instances", "cornell_flat_leaves"):
+        assert st.general_instances == 0, "single spheres under an identity transform stay on the fast path"
+    if policy == T.REBUILD_FORCE_REFIT:
+        assert _walk(nodes, idx) == _walk(_refit_numpy(arrs["tlasNodes"], arrs["tlasInstanceIndices"], want_inst), arrs["tlasInstanceIndices"])
+    else:
+        _check_valid_tlas(nodes, idx, inst)
+    arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = want_blas, inst, nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    ref = _check_frames(orc, renderer, desc, cfg, w, h, spp)
+    if name in ("sphere_instances", "cornell_flat_leaves"):
+        # single-sphere instances: the reference's builder makes the same boxes, so a scene built from the moved spheres on
+        # the host shows the same picture (another TLAS, no rotations, no scales)
+        so = orc.OrcScene()
+
+        class Moved:
+            def __init__(self, inner): self.inner, self.k = inner, 0
+            def add_sphere(self, sph):
+                q = T.Sphere.from_buffer_copy(sp[self.k].tobytes()); self.k += 1
+                return self.inner.add_sphere(q)
+            def __getattr__(self, a): return getattr(self.inner, a)
+        builder(Moved(so))
+        assert so.arrays()["spheres"].tobytes() == sp.tobytes()
+        host, _ = _oracle_render(orc, so.desc(), cfg, w, h, spp)
+        H.assert_outputs_equal(host, ref)
+
+
+def test_update_spheres_errors(renderer):
+    s = engine.Scene(); scenes.build_config2(s); renderer.commit(s)
+    n = len(s.arrays()["spheres"])
+    one = s.arrays()["spheres"][:1]
+    with pytest.raises(engine.HrtError, match="outside spheres"):
+        renderer.update_spheres(n, one)
+    with pytest.raises(engine.HrtError, match="outside spheres"):
+        renderer.update_spheres(-1, one)
+    with pytest.raises(engine.HrtError, match="policy"):
+        renderer.update_spheres(0, one, policy=5)
+    renderer.update_spheres(0, one[:0], T.REBUILD_FORCE_REFIT)

@@ -60,6 +60,18 @@ for n in [int(x) for x in args.counts.split(",")]:
     ms, st = timed(lambda: r.update_instances(ids, xf, T.REBUILD_FORCE_REBUILD))
     row["device_move_rebuild_ms_wall"], row["device_move_rebuild_ms_kernels"] = ms, st.device_ms
     row["frame_ms_moved_device_rebuilt_tree"] = frame_ms()
+    # the same motion expressed as sphere data (hrt_scene_update_spheres): the instances keep their identity transform and
+    # with it the walkers' fast path
+    r.commit(s)
+    sp = s.arrays()["spheres"].copy()
+    for k, f in enumerate("XYZ"):
+        sp["center"][f][1:] += xf[:, [3, 7, 11][k]]
+    ms, st = timed(lambda: r.update_spheres(1, sp[1:], T.REBUILD_FORCE_REFIT))
+    row["device_spheres_refit_ms_wall"], row["device_spheres_refit_ms_kernels"] = ms, st.device_ms
+    row["frame_ms_moved_spheres_refit_tree"] = frame_ms()
+    ms, st = timed(lambda: r.update_spheres(1, sp[1:], T.REBUILD_FORCE_REBUILD))
+    row["device_spheres_rebuild_ms_wall"], row["device_spheres_rebuild_ms_kernels"] = ms, st.device_ms
+    row["frame_ms_moved_spheres_device_rebuilt_tree"] = frame_ms()
     # the reference's way: records + RebuildTLAS on the host, then UploadAll
     affs = []
     for k in range(n):
