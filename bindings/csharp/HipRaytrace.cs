@@ -73,6 +73,7 @@ namespace ILGPU_Raytracing.Engine
     {
         public int action, tlas_nodes, tlas_slots, general_instances;
         public float growth_refit, growth_final, sah_cost, device_ms;
+        public int blas_action; public float blas_growth;
     }
 
     internal static unsafe class HipRaytrace

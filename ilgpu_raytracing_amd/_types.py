@@ -98,7 +98,8 @@ REBUILD_BLAS = 16                                                       # flag o
 
 class BvhUpdateStats(C.Structure):    # hrt_bvh_update_stats
     _fields_ = [("action", C.c_int32), ("tlas_nodes", C.c_int32), ("tlas_slots", C.c_int32), ("general_instances", C.c_int32),
-                ("growth_refit", C.c_float), ("growth_final", C.c_float), ("sah_cost", C.c_float), ("device_ms", C.c_float)]
+                ("growth_refit", C.c_float), ("growth_final", C.c_float), ("sah_cost", C.c_float), ("device_ms", C.c_float),
+                ("blas_action", C.c_int32), ("blas_growth", C.c_float)]
 
 
 class SceneDesc(C.Structure):

@@ -529,6 +529,8 @@ __global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B, int kind)
     hrt_bvh_node* r = B.blasNodes + B.orig[i];
     r->boundsMin.X = q.lo.x; r->boundsMin.Y = q.lo.y; r->boundsMin.Z = q.lo.z;
     r->boundsMax.X = q.hi.x; r->boundsMax.Y = q.hi.y; r->boundsMax.Z = q.hi.z;
+    const float dx = q.hi.x - q.lo.x, dy = q.hi.y - q.lo.y, dz = q.hi.z - q.lo.z;
+    B.sa[i] = 2.f * (dx * dy + dy * dz + dz * dx);
     // links, in the numbering the reference-layout array uses (the uploaded one, or walk order after a rebuild)
     const int cnt = (int)((unsigned)f2i(q.hi.w) >> 28), skip = f2i(q.hi.w) & kEnd, link = f2i(q.lo.w);
     r->skipIndex = skip == kEnd ? -1 : B.orig[skip];
@@ -540,6 +542,42 @@ __global__ void __launch_bounds__(kBlock) k_blas_derive(BlasDevice B, int kind)
         if (l != kEnd) { const int sk = node_skip(B.blas, l); if (sk != kEnd && sk != skip) rr = B.orig[sk]; }
         r->left = l == kEnd ? -1 : B.orig[l]; r->right = rr; r->first = -1; r->count = 0;
     }
+}
+
+// growth of the node boxes of the mesh BLASes since their last build (same measure, same fixed summation order as k_cost)
+__global__ void __launch_bounds__(kBlock) k_blas_growth_partial(BlasDevice B, int kind)
+{
+    __shared__ float s[2][kBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    float lg = 0.f, m = 0.f;
+    if (i < B.nB && B.kind[i] == kind)
+    {
+        const float a = B.sa[i], b = B.saBase[i];
+        if (a > 0.f && b > 0.f) { lg = __logf(a / b); m = 1.f; }
+    }
+    s[0][threadIdx.x] = lg; s[1][threadIdx.x] = m;
+    __syncthreads();
+    for (int d = kBlock / 2; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d) { s[0][threadIdx.x] += s[0][threadIdx.x + d]; s[1][threadIdx.x] += s[1][threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) B.growPartial[2 * blockIdx.x + threadIdx.x] = s[threadIdx.x][0];
+}
+
+__global__ void __launch_bounds__(1024) k_blas_growth(BlasDevice B, int nPartials)
+{
+    __shared__ float s[2][1024];
+    float a0 = 0.f, a1 = 0.f;
+    for (int i = threadIdx.x; i < nPartials; i += 1024) { a0 += B.growPartial[2 * i]; a1 += B.growPartial[2 * i + 1]; }
+    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1)
+    {
+        if ((int)threadIdx.x < d) { s[0][threadIdx.x] += s[0][threadIdx.x + d]; s[1][threadIdx.x] += s[1][threadIdx.x + d]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) B.grow[0] = s[1][0] > 0.f ? __expf(s[0][0] / s[1][0]) : 1.f;
 }
 
 // ------------------------------------------------------------------ BLAS rebuild of one mesh
@@ -764,6 +802,13 @@ hipError_t blas_refit(const BlasDevice& B, int kind, hipStream_t s)
         for (long long lo = B.directMax; lo < B.nB; lo *= 64)
             k_blas_refit_level<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
     k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
+    return hipGetLastError();
+}
+
+hipError_t blas_growth(const BlasDevice& B, int kind, hipStream_t s)
+{
+    k_blas_growth_partial<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
+    k_blas_growth<<<1, 1024, 0, s>>>(B, blocks_for(B.nB));
     return hipGetLastError();
 }
 

@@ -297,8 +297,9 @@ struct DeviceState {
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
-    void* blaux[8] = {};                       // parent, nchild, subend, orig, arrive, ids of the TriMesh instances, kind, ids of the SphereSet instances
+    void* blaux[12] = {};                      // parent, nchild, subend, orig, arrive, ids of the TriMesh instances, kind, ids of the SphereSet instances, sa, saBase, growPartial, grow
     int n_mesh_inst = 0, n_sphere_inst = 0;
+    bool blas_base_valid = false;              // saBase holds the node areas of the mesh BLASes as they were last built
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
@@ -449,8 +450,8 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
-    for (int i = 0; i < 8; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
-    d.bl = BlasDevice{}; d.n_mesh_inst = 0; d.n_sphere_inst = 0;
+    for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
+    d.bl = BlasDevice{}; d.n_mesh_inst = 0; d.n_sphere_inst = 0; d.blas_base_valid = false;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1357,10 +1358,12 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             {
                 const size_t nBq = ph.blas.size();
                 static const int32_t none = 0;
-                const void* bsrc[8] = {ph.bparent.data(), ph.bnchild.data(), ph.bsubend.data(), ph.borig.data(), nullptr,
-                                       ph.meshInst.empty() ? &none : ph.meshInst.data(), ph.bkind.data(), ph.sphereInst.empty() ? &none : ph.sphereInst.data()};
-                const size_t bb[8] = {nBq * 4, nBq * 4, nBq * 4, nBq * 4, nBq * 4, std::max<size_t>(ph.meshInst.size(), 1) * 4, nBq * 4, std::max<size_t>(ph.sphereInst.size(), 1) * 4};
-                for (int i = 0; i < 8; i++)
+                const void* bsrc[12] = {ph.bparent.data(), ph.bnchild.data(), ph.bsubend.data(), ph.borig.data(), nullptr,
+                                        ph.meshInst.empty() ? &none : ph.meshInst.data(), ph.bkind.data(), ph.sphereInst.empty() ? &none : ph.sphereInst.data(),
+                                        nullptr, nullptr, nullptr, nullptr};
+                const size_t bb[12] = {nBq * 4, nBq * 4, nBq * 4, nBq * 4, nBq * 4, std::max<size_t>(ph.meshInst.size(), 1) * 4, nBq * 4, std::max<size_t>(ph.sphereInst.size(), 1) * 4,
+                                       nBq * 4, nBq * 4, ((nBq + 255) / 256) * 8, 16};
+                for (int i = 0; i < 12; i++)
                 {
                     HIPCHK(c, hipMalloc(&d.blaux[i], bb[i]));
                     if (bsrc[i]) HIPCHK(c, hipMemcpyAsync(d.blaux[i], bsrc[i], bb[i], hipMemcpyHostToDevice, d.stream));
@@ -1371,6 +1374,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
                 B.triPrimIdxW = (int32_t*)d.scene[6]; B.triMatIndex = (const int32_t*)d.scene[11]; B.materials = (const hrt_material*)d.scene[12];
                 B.nMaterials = (int)s->n_materials; B.texLen = (int)(s->n_texInfos > 0 ? s->n_texInfos : 1);
                 B.spherePrimIdx = (const int32_t*)d.scene[4]; B.spheres = (const hrt_sphere*)d.scene[5]; B.kind = (int*)d.blaux[6];
+                B.sa = (float*)d.blaux[8]; B.saBase = (float*)d.blaux[9]; B.growPartial = (float*)d.blaux[10]; B.grow = (float*)d.blaux[11];
                 B.positions = (hrt_float3*)d.scene[7]; B.blas = (NodeQ*)d.packed[2]; B.ftri = (FTri*)d.packed[3];
                 B.parent = (int*)d.blaux[0]; B.nchild = (int*)d.blaux[1]; B.subend = (int*)d.blaux[2]; B.orig = (int*)d.blaux[3]; B.arrive = (int*)d.blaux[4];
                 B.nB = (int)s->n_blasNodes; B.nSlots = (int)s->n_triPrimIdx; B.directMax = 63;
@@ -1554,18 +1558,50 @@ int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_f
     if (policy >= 0) policy &= ~HRT_REBUILD_BLAS;
     if (rebuildBlas && !c->blas_rebuild_ok)
         return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: a triangle-mesh BLAS of this scene cannot be rebuilt on the device (its leaves do not list their triangles in one region of triPrimIdx)");
-    return apply_update(c, policy, "hrt_scene_update_positions", [&](DeviceState& d, std::vector<void*>&) -> int {
-        if (n > 0) HIPCHK(c, hipMemcpyAsync((hrt_float3*)d.scene[7] + first, positions, (size_t)n * sizeof(hrt_float3), hipMemcpyHostToDevice, d.stream));
-        if (rebuildBlas && !c->mesh_jobs.empty())
-        {
+    int blasAction = 0; float blasGrowth = 0.f;
+    const int rc = apply_update(c, policy, "hrt_scene_update_positions", [&](DeviceState& d, std::vector<void*>&) -> int {
+        const bool meshes = d.n_mesh_inst > 0;
+        auto keep_base = [&]() -> int {
+            HIPCHK(c, hipMemcpyAsync(d.bl.saBase, d.bl.sa, (size_t)d.bl.nB * 4, hipMemcpyDeviceToDevice, d.stream));
+            d.blas_base_valid = true;
+            return HRT_OK;
+        };
+        auto rebuild_all = [&]() -> int {
             int rc2 = ensure_lbvh_scratch(c, d);
             if (rc2 != HRT_OK) return rc2;
             for (const MeshJob& J : c->mesh_jobs) HIPCHK(c, blas_rebuild_mesh(d.tl, d.bl, J, d.stream, nullptr));
+            return HRT_OK;
+        };
+        int rc2;
+        if (meshes && !d.blas_base_valid && !rebuildBlas)
+        {   // node areas of the BLASes as they were built: taken once, before the first vertex moves
+            HIPCHK(c, blas_refit(d.bl, 1, d.stream));
+            if ((rc2 = keep_base()) != HRT_OK) return rc2;
         }
-        if (d.n_mesh_inst > 0) HIPCHK(c, blas_refit(d.bl, 1, d.stream));
+        if (n > 0) HIPCHK(c, hipMemcpyAsync((hrt_float3*)d.scene[7] + first, positions, (size_t)n * sizeof(hrt_float3), hipMemcpyHostToDevice, d.stream));
+        bool rebuilt = false;
+        if (rebuildBlas && !c->mesh_jobs.empty()) { if ((rc2 = rebuild_all()) != HRT_OK) return rc2; rebuilt = true; }
+        if (meshes) HIPCHK(c, blas_refit(d.bl, 1, d.stream));
+        float growth = 0.f;
+        if (meshes && !rebuilt)
+        {
+            HIPCHK(c, blas_growth(d.bl, 1, d.stream));
+            HIPCHK(c, hipMemcpyAsync(&growth, d.bl.grow, 4, hipMemcpyDeviceToHost, d.stream));
+            HIPCHK(c, hipStreamSynchronize(d.stream));
+            if (policy == HRT_REBUILD_AUTO && growth > kAutoRebuildGrowth && c->blas_rebuild_ok && !c->mesh_jobs.empty())
+            {
+                if ((rc2 = rebuild_all()) != HRT_OK) return rc2;
+                HIPCHK(c, blas_refit(d.bl, 1, d.stream));
+                rebuilt = true;
+            }
+        }
+        if (rebuilt && (rc2 = keep_base()) != HRT_OK) return rc2;
+        if (&d == &c->dev[0]) { blasAction = meshes ? (rebuilt ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT) : 0; blasGrowth = growth; }
         HIPCHK(c, tlas_rebound_instances(d.tl, (const int32_t*)d.blaux[5], d.n_mesh_inst, d.stream));
         return HRT_OK;
     }, st);
+    if (rc == HRT_OK && st) { st->blas_action = blasAction; st->blas_growth = blasGrowth; }
+    return rc;
 }
 
 int hrt_scene_update_spheres(hrt_ctx* c, int64_t first, int64_t n, const hrt_sphere* spheres, int32_t policy, hrt_bvh_update_stats* st)

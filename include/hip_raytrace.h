@@ -195,6 +195,8 @@ typedef struct hrt_bvh_update_stats {
     float   growth_final;     /* the same for the tree now in use (1 after a rebuild)                          */
     float   sah_cost;         /* of the tree now in use: sum(area x (leaf ? count : 1)) / area(root)            */
     float   device_ms;        /* HIP-event time of the device work on device slot 0                            */
+    int32_t blas_action;      /* hrt_scene_update_positions: what happened to the mesh BLASes (0 none, refit, rebuild) */
+    float   blas_growth;      /* ... and the growth of their node boxes after the refit (0: not measured)       */
 } hrt_bvh_update_stats;
 
 int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32_t n, const hrt_affine3x4* objectToWorld,
@@ -205,7 +207,8 @@ int  hrt_scene_update_instances(hrt_ctx* ctx, const int32_t* instance_ids, int32
  * every triangle-mesh BLAS keeps its topology and gets its triangle records and boxes recomputed bottom-up on the device
  * (BoundsOfTriangle over the items of each node, Scene.cs:423-429,597-605), the world bounds of the mesh instances are
  * re-derived from the new root boxes (TransformAABB, Scene.cs:560-580), and the TLAS is refitted / rebuilt per `policy`
- * as in hrt_scene_update_instances.  policy | HRT_REBUILD_BLAS first gives every triangle-mesh BLAS a new topology for the
+ * as in hrt_scene_update_instances; with HRT_REBUILD_AUTO the mesh BLASes are rebuilt too when their boxes have grown, in the
+ * geometric mean, to more than 1.5 x their area at the last build.  policy | HRT_REBUILD_BLAS first gives every triangle-mesh BLAS a new topology for the
  * new positions: a Morton-order LBVH over its triangles with leaves of <= 4 like the reference's BLAS, built on the device
  * into the node range and the leaf region of triPrimIdx the mesh already owns (blasNodeCount of its instance shrinks to
  * the new node count).  Another BLAS visits triangles in another order: pixels where two triangles are hit at bit-equal

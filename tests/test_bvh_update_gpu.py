@@ -666,3 +666,34 @@ def test_update_spheres_errors(renderer):
     with pytest.raises(engine.HrtError, match="policy"):
         renderer.update_spheres(0, one, policy=5)
     renderer.update_spheres(0, one[:0], T.REBUILD_FORCE_REFIT)
+
+
+def test_auto_rebuilds_a_mesh_blas_when_its_boxes_grow(orc, renderer):
+    builder, cfg, w, h, spp = MESH_SCENES["blob_24x24"]
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    arrs = s.arrays()
+    pos = np.stack([arrs["meshPositions"][f] for f in "XYZ"], axis=1)
+    host_nodes = int(arrs["instances"][arrs["instances"]["type"] == 2][0]["blasNodeCount"])
+    st = renderer.update_positions(0, (pos * np.float32(1.01)).astype(np.float32), T.REBUILD_AUTO)
+    assert st.blas_action == T.REBUILD_FORCE_REFIT and 0.9 < st.blas_growth < 1.5
+    assert renderer.download_array("triPrimIdx").tobytes() == arrs["triPrimIdx"].tobytes()
+    # every vertex to a pseudo-random place inside the old bounds: neighbours in the tree end up far apart
+    rng = np.random.default_rng(3)
+    new = (pos[rng.permutation(len(pos))]).astype(np.float32)
+    st = renderer.update_positions(0, new, T.REBUILD_AUTO)
+    assert st.blas_action == T.REBUILD_FORCE_REBUILD and st.blas_growth > 1.5
+    got = {k: renderer.download_array(k) for k in ("blasNodes", "triPrimIdx")}
+    nodes, idx, inst = _download(renderer)
+    mi = inst[inst["type"] == 2][0]
+    assert 0 < mi["blasNodeCount"] <= host_nodes
+    for k, f in enumerate("XYZ"):
+        arrs["meshPositions"][f] = new[:, k]
+    arrs["blasNodes"], arrs["triPrimIdx"], arrs["instances"] = got["blasNodes"], got["triPrimIdx"], inst
+    want_blas, want_inst = _refit_blas_numpy(arrs)
+    assert want_blas.tobytes() == got["blasNodes"].tobytes() and want_inst.tobytes() == inst.tobytes()
+    arrs["tlasNodes"], arrs["tlasInstanceIndices"] = nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    _check_frames(orc, renderer, desc, cfg, w, h, spp)
+    # the rebuilt tree is the new base: the same positions again only refit
+    st = renderer.update_positions(0, new, T.REBUILD_AUTO)
+    assert st.blas_action == T.REBUILD_FORCE_REFIT and abs(st.blas_growth - 1.0) < 1e-3
