@@ -30,6 +30,11 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 python tools/kstats.py $OUT/prof_c4 | head -12 | tee -a $OUT/progress.log
 echo "== all configs, kernel organisations" | tee -a $OUT/progress.log
 timeout -k 10 600 python tools/ab_bench.py --configs 2,3,4,5 --frames 5 2>&1 | tee -a $OUT/progress.log
+echo "== scene updates on the device (TLAS refit / rebuild, sphere and vertex updates)" | tee -a $OUT/progress.log
+timeout -k 10 300 python tools/bvh_update_bench.py --counts 10000,100000 --out $OUT/bvh_update_bench.json > $OUT/bvh_update_bench.log 2>&1; echo "bvh_update_bench rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 python tools/mesh_update_bench.py --out $OUT/mesh_update_bench.json > $OUT/mesh_update_bench.log 2>&1; echo "mesh_update_bench rc=$?" | tee -a $OUT/progress.log
+timeout -k 10 300 python bench.py --config 3 --device-tlas --cpu-seconds 0 > $OUT/bench_c3_device_tlas.json 2> $OUT/bench_c3_device_tlas.err; echo "bench --device-tlas rc=$?" | tee -a $OUT/progress.log
+cut -c1-400 $OUT/bench_c3_device_tlas.json | tee -a $OUT/progress.log
 STATS=ilgpu_raytracing_amd/csrc/variants/libhip_raytrace_stats.so
 if [ -e $STATS ]; then
   echo "== walker phase statistics (variant build -DHRT_WALK_STATS)" | tee -a $OUT/progress.log
