@@ -778,7 +778,8 @@ hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const Mes
     k_leaf_counts<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n);
     if ((e = hipMemcpyAsync(counts, T.leafCounts, sizeof(counts), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    int limit = 4;
+    int limit = 4;                                   // the reference's BLAS leaf size; HRT_BLAS_LEAF_LIMIT = 4..14 for experiments
+    if (const char* e2 = getenv("HRT_BLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 4 && v <= 14) limit = v; }
     while (limit < 14 && 2 * counts[limit] - 1 > J.nodeCap) limit++;
     if (2 * counts[limit] - 1 > J.nodeCap) return hipErrorInvalidValue;
     if (leafLimitOut) *leafLimitOut = limit;
