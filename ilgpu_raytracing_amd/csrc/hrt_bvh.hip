@@ -796,11 +796,11 @@ hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const Mes
 hipError_t blas_refit(const BlasDevice& B, int kind, hipStream_t s)
 {
     hipError_t e;
-    if ((e = hipMemsetAsync(B.arrive, 0, (size_t)B.nB * sizeof(int), s)) != hipSuccess) return e;
+    if (B.directMax <= 1 && (e = hipMemsetAsync(B.arrive, 0, (size_t)B.nB * sizeof(int), s)) != hipSuccess) return e;   // only the climb counts arrivals
     if (kind == 1 && B.nSlots > 0) k_tri_records<<<blocks_for(B.nSlots), kBlock, 0, s>>>(B);
     k_blas_refit<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
     if (B.directMax > 1)
-        for (long long lo = B.directMax; lo < B.nB; lo *= 64)
+        for (long long lo = B.directMax; lo < B.maxRange[kind]; lo *= 64)
             k_blas_refit_level<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind, (int)lo, (int)std::min<long long>(lo * 64, 0x7FFFFFFF));
     k_blas_derive<<<blocks_for(B.nB), kBlock, 0, s>>>(B, kind);
     return hipGetLastError();
@@ -886,7 +886,7 @@ hipError_t tlas_finish(const TlasDevice& T, hipStream_t s)
 {
     hipError_t e;
     if ((e = hipMemsetAsync(T.flags, 0, 4 * sizeof(int), s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(T.arrive, 0, (size_t)T.nT * sizeof(int), s)) != hipSuccess) return e;
+    if (T.directMax <= 1 && (e = hipMemsetAsync(T.arrive, 0, (size_t)T.nT * sizeof(int), s)) != hipSuccess) return e;   // only the climb counts arrivals
     if (T.nTI > 0) k_leaf_slots<<<blocks_for(T.nTI), kBlock, 0, s>>>(T);
     k_refit<<<blocks_for(T.nT), kBlock, 0, s>>>(T);
     if (T.directMax > 1)
