@@ -46,3 +46,14 @@ def test_required_files_exist():
     for p in ("bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/hip_raytrace.h", "include/hrt_types.h",
               "oracle/orc_kernels.hpp", "oracle/Makefile", "tests/golden/make_golden.py", "profiles"):
         assert os.path.exists(os.path.join(ROOT, p)), p
+
+
+def test_tools_and_package_compile():
+    """Every script under tools/ and the package byte-compile (they are only run on the GPU box otherwise)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "ilgpu_raytracing_amd", "*.py")) + \
+        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        compile(open(f).read(), f, "exec")
