@@ -90,8 +90,19 @@ int main(int argc, char** argv)
     CHECK(ctx, hrt_render_frame(ctx, &p, &opts, &out, NULL));
     unsigned long long sum = 0;
     for (long long i = 0; i < (long long)width * height; i++) sum += (unsigned)color[i] & 0xFFFFFFu;
+
+    /* BvhManager.BuildOrRefit(scene, ForceRebuild) on the device: nothing moved, the TLAS is rebuilt there; same picture */
+    hrt_bvh_update_stats us;
+    CHECK(ctx, hrt_scene_update_instances(ctx, NULL, 0, NULL, HRT_REBUILD_FORCE_REBUILD, &us));
+    CHECK(ctx, hrt_reset_history(ctx));
+    int* color2 = (int*)malloc((size_t)width * height * sizeof(int));
+    out.color = color2;
+    CHECK(ctx, hrt_render_frame(ctx, &p, &opts, &out, NULL));
+    const int same = memcmp(color, color2, (size_t)width * height * sizeof(int)) == 0;
     printf("{\"host\": \"C\", \"width\": %d, \"height\": %d, \"spp\": %d, \"frames\": %d, \"rays_per_frame\": %.0f, \"kernel_ms_per_frame\": %.4f, "
-           "\"mrays_per_s\": %.1f, \"color_checksum\": %llu}\n", width, height, spp, st.frames, rays, ms, rays / ms / 1e3, sum);
+           "\"mrays_per_s\": %.1f, \"color_checksum\": %llu, \"device_tlas_nodes\": %d, \"device_tlas_ms\": %.3f, \"device_tlas_same_picture\": %s}\n",
+           width, height, spp, st.frames, rays, ms, rays / ms / 1e3, sum, us.tlas_nodes, us.device_ms, same ? "true" : "false");
+    free(color2);
     free(color);
     hrt_destroy(ctx);
     hrth_scene_free(scene);

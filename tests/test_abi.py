@@ -103,3 +103,4 @@ def test_plain_c_host_renders(hrt_lib, tmp_path):
     runs = [json.loads(subprocess.run([exe, "320", "180", "2", "3"], capture_output=True, text=True, check=True).stdout) for _ in range(2)]
     assert runs[0]["color_checksum"] == runs[1]["color_checksum"] and runs[0]["rays_per_frame"] == runs[1]["rays_per_frame"]
     assert runs[0]["host"] == "C" and runs[0]["frames"] == 3 and runs[0]["mrays_per_s"] > 0 and runs[0]["rays_per_frame"] > 320 * 180
+    assert runs[0]["device_tlas_same_picture"] is True and runs[0]["device_tlas_nodes"] > 0
