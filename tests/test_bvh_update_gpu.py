@@ -697,3 +697,49 @@ def test_auto_rebuilds_a_mesh_blas_when_its_boxes_grow(orc, renderer):
     # the rebuilt tree is the new base: the same positions again only refit
     st = renderer.update_positions(0, new, T.REBUILD_AUTO)
     assert st.blas_action == T.REBUILD_FORCE_REFIT and abs(st.blas_growth - 1.0) < 1e-3
+
+
+def test_big_mesh_refit_and_rebuild(orc, renderer):
+    """Config 4's 100 352-triangle mesh (65 535 BLAS nodes): the level launches of the refit above the direct subtrees, the
+    radix sort of real Morton keys and the leaf-limit search of the BLAS rebuild, checked against the numpy restatement and
+    the oracle at a small resolution."""
+    builder, cfg, w, h, spp = (lambda b: scenes.build_config4(b)), scenes.CONFIGS[4], 160, 90, 1
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    arrs = s.arrays()
+    pos = np.stack([arrs["meshPositions"][f] for f in "XYZ"], axis=1)
+    new = (pos * (1.0 + 0.05 * np.sin(4.0 * pos[:, [1, 2, 0]] + 0.2))).astype(np.float32)
+    st = renderer.update_positions(0, new, T.REBUILD_FORCE_REFIT)
+    assert st.blas_action == T.REBUILD_FORCE_REFIT
+    for k, f in enumerate("XYZ"):
+        arrs["meshPositions"][f] = new[:, k]
+    want_blas, want_inst = _refit_blas_numpy(arrs)
+    assert renderer.download_array("blasNodes").tobytes() == want_blas.tobytes()
+    nodes, idx, inst = _download(renderer)
+    assert inst.tobytes() == want_inst.tobytes()
+    arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = want_blas, inst, nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    ref, ost = _oracle_render(orc, desc, cfg, w, h, spp)
+    got, gst = _gpu_render(renderer, cfg, w, h, spp, T.FLAG_COUNTERS)
+    H.assert_outputs_equal(ref, got)
+    assert gst.k[1].as_dict() == ost.k[1].as_dict()
+    # new topology on the device
+    st = renderer.update_positions(0, new[:0], T.REBUILD_FORCE_REFIT | T.REBUILD_BLAS)
+    got_b = {k: renderer.download_array(k) for k in ("blasNodes", "triPrimIdx")}
+    nodes, idx, inst = _download(renderer)
+    mi = np.nonzero(inst["type"] == 2)[0][0]
+    n_items = int(inst[mi]["primIndexCount"])
+    assert 0 < inst[mi]["blasNodeCount"] <= arrs["instances"][mi]["blasNodeCount"]
+    region = got_b["triPrimIdx"][n_items:2 * n_items] if int(inst[mi]["primIndexFirst"]) == 0 else None
+    arrs["blasNodes"], arrs["triPrimIdx"], arrs["instances"] = got_b["blasNodes"], got_b["triPrimIdx"], inst
+    want_blas, want_inst = _refit_blas_numpy(arrs)
+    assert want_blas.tobytes() == got_b["blasNodes"].tobytes() and want_inst.tobytes() == inst.tobytes()
+    if region is not None:
+        assert sorted(region.tolist()) == sorted(arrs["triPrimIdx"][:n_items].tolist()), "every triangle in exactly one leaf slot"
+    arrs["tlasNodes"], arrs["tlasInstanceIndices"] = nodes, idx
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    ref, ost = _oracle_render(orc, desc, cfg, w, h, spp)
+    for flags in (T.FLAG_COUNTERS, 0, T.FLAG_COUNTERS | T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT):
+        got, gst = _gpu_render(renderer, cfg, w, h, spp, flags)
+        H.assert_outputs_equal(ref, got)
+        if flags & T.FLAG_COUNTERS:
+            assert gst.k[1].as_dict() == ost.k[1].as_dict()
