@@ -296,6 +296,7 @@ struct DeviceState {
     void* tlaux[10] = {};                      // parent, nchild, arrive, scanIn, scanOut, sa, flags, cost, saBase, scanTmp + costPartial
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
+    bool tlas_lbvh = false;                    // the TLAS in use was BUILT on the device (Auto rebuilds an uploaded tree once: the LBVH walks faster)
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
     void* blaux[12] = {};                      // parent, nchild, subend, orig, arrive, ids of the TriMesh instances, kind, ids of the SphereSet instances, sa, saBase, growPartial, grow
     int n_mesh_inst = 0, n_sphere_inst = 0;
@@ -449,7 +450,7 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
     if (d.tlscratch) (void)hipFree(d.tlscratch);
-    d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false;
+    d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
     for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
     d.bl = BlasDevice{}; d.n_mesh_inst = 0; d.n_sphere_inst = 0; d.blas_base_valid = false;
 }
@@ -1473,6 +1474,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         std::vector<void*> staged;
         if ((rc = mutate(d, staged)) != HRT_OK) return rc;
         int action = policy == HRT_REBUILD_FORCE_REBUILD ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT;
+        if (policy == HRT_REBUILD_AUTO && !d.tlas_lbvh) action = HRT_REBUILD_FORCE_REBUILD;   // an uploaded tree: the device-built one costs as much as a refit and walks faster
         float growthRefit = 0.f;
         int rebuiltLeaves = 0;
         if (action == HRT_REBUILD_FORCE_REFIT)
@@ -1489,6 +1491,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             if ((rc = finish_and_read()) != HRT_OK) return rc;
             if ((rc = keep_as_base()) != HRT_OK) return rc;
             h_cost[0] = 1.f;                                            // as built
+            d.tlas_lbvh = true;
         }
         HIPCHK(c, hipEventRecord(e1, d.stream));
         HIPCHK(c, hipEventSynchronize(e1));

@@ -176,7 +176,9 @@ int  hrt_scene_upload(hrt_ctx* ctx, const hrt_scene_desc* scene);
  *   - HRT_REBUILD_FORCE_REFIT keeps the TLAS topology and recomputes every box bottom-up;
  *   - HRT_REBUILD_FORCE_REBUILD builds a new TLAS over ALL instances (as RebuildTLAS does) with a Morton-order
  *     LBVH, leaves of <= 2 instances;
- *   - HRT_REBUILD_AUTO refits, and rebuilds if the boxes of the refitted tree have grown, in the geometric mean
+ *   - HRT_REBUILD_AUTO rebuilds a tree that was uploaded (once: the device-built tree costs about as much as a refit
+ *     and walks faster than the reference's median split), afterwards refits, and rebuilds again if the boxes of the
+ *     refitted tree have grown, in the geometric mean
  *     over all nodes, to more than 1.5 x the surface area they had when the tree was last built (uploaded or
  *     rebuilt): a measure neither one far-flung instance nor one huge instance dominates.
  * n may be 0 (re-derive / rebuild only).  Blocking; every device of the context is updated.  The TLAS of a scene

@@ -240,6 +240,8 @@ def test_auto_refits_small_moves_and_rebuilds_when_the_tree_degrades(orc, render
     ids = list(range(1, n))
     small = [scenes.rotation_affine("y", 0.0, 1.0, (0.01 * (i % 3), 0.0, 0.0)) for i in ids]
     st = renderer.update_instances(ids, small, T.REBUILD_AUTO)
+    assert st.action == T.REBUILD_FORCE_REBUILD and st.growth_final == 1.0, "an uploaded tree is replaced by the device-built one at the first Auto"
+    st = renderer.update_instances(ids, [scenes.rotation_affine("y", 0.0, 1.0, (0.02 * (i % 3), 0.01, 0.0)) for i in ids], T.REBUILD_AUTO)
     assert st.action == T.REBUILD_FORCE_REFIT and 0.9 < st.growth_refit <= 1.5 and st.growth_final == st.growth_refit
     # every instance to the mirrored position: neighbours in the tree end up far apart
     far = [scenes.rotation_affine("y", 0.0, 1.0, (((i * 7919) % 13) - 6.0, 0.0, ((i * 104729) % 11) - 5.0)) for i in ids]
