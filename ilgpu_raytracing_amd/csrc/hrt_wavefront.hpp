@@ -38,7 +38,10 @@
 
 namespace hrt {
 
-constexpr int kRange = 256;                  // slots per range (one wave owns one range)
+#ifndef HRT_RANGE
+#define HRT_RANGE 256
+#endif
+constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); <= 256: shade tags a vertex with its request's offset in 8 bits
 
 struct Planes {                              // plane p of slot i = base[p * stride + i]
     float* base; long long stride;
