@@ -39,9 +39,10 @@
 namespace hrt {
 
 #ifndef HRT_RANGE
-#define HRT_RANGE 256
+#define HRT_RANGE 512
 #endif
-constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); <= 256: shade tags a vertex with its request's offset in 8 bits
+constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); 256 / 512 / 1024 measured, DESIGN.md 8
+static_assert(kRange % 64 == 0 && kRange <= 65536, "a range is a whole number of waves; shade tags a vertex with its request's offset in 16 bits");
 
 struct Planes {                              // plane p of slot i = base[p * stride + i]
     float* base; long long stride;
@@ -64,7 +65,7 @@ enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG =
 // ray request written by wf_shade for the same slot
 // RQ_A = (o.xyz, d.x)  RQ_B = (d.yz, flags, rng)  RQ_H = raw winner of the closest-hit walk (t, tObj, leaf slot, primitive): 16-byte records
 enum { RQ_A = 0, RQ_B = 4, R_T = 8, RQ_H = 11, R_PLANES = 15 };
-enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROTE also in V_MAT bit 17); RF_SHADOW: bits 8..15 = the vertex' shadow request, relative to its range
+enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROTE also in V_MAT bit 17); RF_SHADOW: bits 8..23 = the vertex' shadow request, relative to its range
 // shadow request (compacted per range)
 // SQ_A = (o.xyz, d.x)  SQ_B = (d.yz, slot in range, add.x): 16-byte records; add.yz in two planes
 enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_VIS = 10, S_PLANES = 11 };      // S_VIS: 1 once the walk found the request unoccluded
@@ -547,7 +548,7 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
             Li = V.ld3(V_LI, slot);
             if (flg & RF_SHADOW)
             {   // direct light of this vertex, if its shadow walk found the light unoccluded (:286/:291)
-                const long long q = base + ((flg >> 8) & 0xFF);
+                const long long q = base + ((flg >> 8) & 0xFFFF);
                 if (W.SQ.ldi(S_VIS, q)) Li = Li + mk3(W.SQ.ld4(SQ_B, q).w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q));
             }
             if (!dead)
