@@ -39,9 +39,9 @@
 namespace hrt {
 
 #ifndef HRT_RANGE
-#define HRT_RANGE 512
+#define HRT_RANGE 384
 #endif
-constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); 256 / 512 / 1024 measured, DESIGN.md 8
+constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); 256 / 384 / 512 / 1024 measured, DESIGN.md 8
 static_assert(kRange % 64 == 0 && kRange <= 65536, "a range is a whole number of waves; shade tags a vertex with its request's offset in 16 bits");
 
 struct Planes {                              // plane p of slot i = base[p * stride + i]
