@@ -130,7 +130,8 @@ hrt_wf_shade_kernel(FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long lo
 }
 
 #ifndef HRT_WALK_BLOCKS_PER_CU
-#define HRT_WALK_BLOCKS_PER_CU 8               // 8 workgroups x 4 waves = the 32 wave slots of a CU at <= 64 VGPRs
+#define HRT_WALK_BLOCKS_PER_CU 4               // persistent workgroups per CU of a chained walk launch: 16 of the 32 wave slots a CU has at <= 64 VGPRs.
+                                               // Fewer rays in flight, but their tree nodes stay in L1 / L2: 3 / 4 / 5 / 6 / 8 / 12 measured
 #endif
 constexpr int kWalkBlocksPerCU = HRT_WALK_BLOCKS_PER_CU;
 // Walk launches either give every wave one path range (static) or let persistent waves pull ranges until none is

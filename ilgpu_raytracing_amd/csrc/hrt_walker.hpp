@@ -22,9 +22,9 @@ namespace hrt {
 
 enum { M_IDLE = 0, M_TLAS = 1, M_TLEAF = 2, M_BLAS = 3, M_BLEAF = 4, M_DONE = 5 };
 #ifndef HRT_REFILL_MIN
-#define HRT_REFILL_MIN 16
+#define HRT_REFILL_MIN 24
 #endif
-constexpr int kRefillMin = HRT_REFILL_MIN;      // refill when at least this many lanes are idle (or none is active)
+constexpr int kRefillMin = HRT_REFILL_MIN;      // refill when at least this many lanes are idle (or none is active); 8 / 16 / 24 / 32 measured, DESIGN.md 8
 constexpr int kNodeBurst = 6;       // max node steps per iteration while most lanes are still walking
 #ifndef HRT_LOOKAHEAD
 #define HRT_LOOKAHEAD 2             // records fetched per node step (1 = no lookahead)
