@@ -60,8 +60,13 @@ hrt_primary_kernel(TR tr, FrameK k, DGBuffer gb, TileMap tm, unsigned long long*
 #ifndef HRT_PT_WAVES
 #define HRT_PT_WAVES 4   // 128-VGPR cap: 4 waves/SIMD hide the dependent node loads better than 2 at 204 VGPRs (measured)
 #endif
+// The leaf-sweep tracer is the exception: at 5 waves/SIMD (102 VGPRs, 112 bytes of scratch per lane) the fused kernel of
+// config 2 is 2 % faster than at 4 (VALU-bound: one more wave to issue from is worth the spill traffic); 6 and 3 lose 12 %.
+// Every other tracer spills two to four times as much there and keeps 4.
+template <class TR> struct PtWaves { static constexpr int value = HRT_PT_WAVES; };
+template <> struct PtWaves<TracerFlat> { static constexpr int value = HRT_PT_WAVES + 1; };
 template <class TR, bool COUNT>
-__global__ void __launch_bounds__(256, HRT_PT_WAVES)
+__global__ void __launch_bounds__(256, PtWaves<TR>::value)
 hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
                       long long nPix, TileMap tm, unsigned long long* counters)
 {
