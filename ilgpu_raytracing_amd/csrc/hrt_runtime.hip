@@ -81,7 +81,7 @@ hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir 
 // independent up to the ordered sum and the last-writer reservoir, so the launch is cut into sample groups (workgroup =
 // tile x group) and a resolve pass puts the pixel together in sample order: same values, several rounds of shorter waves.
 template <class TR>
-__global__ void __launch_bounds__(256, HRT_PT_WAVES)
+__global__ void __launch_bounds__(256, PtWaves<TR>::value)
 hrt_path_trace_split_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
                             long long nPix, TileMap tm, hrt_float3* li, float* stage, int nGroups, int perGroup)
 {
