@@ -1010,7 +1010,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     if (mega || k.maxDepth > 64)
     {
         const dim3 grid(tm.nTiles), block(64 * tm.wpb);
-        // sample groups when the tile gives the machine less than ~3 rounds of waves
+        // sample groups when the tile gives the machine less than ~5 rounds of waves
         static const int splitEnv = getenv("HRT_SPLIT") ? atoi(getenv("HRT_SPLIT")) : -1;          // A/B knob: 0 never, n > 0 force n groups
         const int sppN = k.spp > 1 ? k.spp : 1;
         const long long waves = (long long)tm.nTiles * tm.wpb, slots = (long long)d.n_cu * 4 * HRT_PT_WAVES;
@@ -1018,7 +1018,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         if (!count && k.maxDepth <= 64 && sppN > 1 && waves > 0)
         {
             if (splitEnv > 0) nGroups = std::min(splitEnv, sppN);
-            else if (splitEnv < 0 && waves < 3 * slots) nGroups = (int)std::min<long long>(std::min(sppN, 8), (4 * slots + waves - 1) / waves);
+            else if (splitEnv < 0 && waves < 5 * slots) nGroups = (int)std::min<long long>(std::min(sppN, 8), (16 * slots + waves - 1) / waves);   // config 2 over N = 2 / 4 / 8 ranks: 4 groups each (1.111 -> 1.079, 0.593 -> 0.555, 0.296 ms)
         }
         if (nGroups > 1)
         {
