@@ -779,7 +779,7 @@ hipError_t blas_rebuild_mesh(const TlasDevice& T, const BlasDevice& B, const Mes
     if ((e = hipMemcpyAsync(counts, T.leafCounts, sizeof(counts), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
     int limit = 4;                                   // the reference's BLAS leaf size; HRT_BLAS_LEAF_LIMIT = 4..14 for experiments
-    if (const char* e2 = getenv("HRT_BLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 4 && v <= 14) limit = v; }
+    if (const char* e2 = HRT_ENV("HRT_BLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 4 && v <= 14) limit = v; }
     while (limit < 14 && 2 * counts[limit] - 1 > J.nodeCap) limit++;
     if (2 * counts[limit] - 1 > J.nodeCap) return hipErrorInvalidValue;
     if (leafLimitOut) *leafLimitOut = limit;
@@ -868,7 +868,7 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s, int* leavesOut)
     k_lbvh_inner<<<blocks_for(n - 1), kBlock, 0, s>>>(T, n, 1);
     if ((e = hipMemsetAsync(T.lstart, 0, (size_t)(n + 1) * sizeof(int), s)) != hipSuccess) return e;
     int limit = 2;                                   // the reference's TLAS leaf size; HRT_TLAS_LEAF_LIMIT = 1..14 for experiments
-    if (const char* e2 = getenv("HRT_TLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 1 && v <= 14) limit = v; }
+    if (const char* e2 = HRT_ENV("HRT_TLAS_LEAF_LIMIT")) { const int v = atoi(e2); if (v >= 1 && v <= 14) limit = v; }
     k_mark_leaves<<<blocks_for(2 * n - 1), kBlock, 0, s>>>(T, n, limit);
     bytes = T.iscanTmpBytes;
     if ((e = hipcub::DeviceScan::ExclusiveSum(T.iscanTmp, bytes, (const int*)T.lstart, T.lsum, n + 1, s)) != hipSuccess) return e;

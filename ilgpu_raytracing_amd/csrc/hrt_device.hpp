@@ -833,9 +833,10 @@ HRT_D void primary_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, int 
 // SPLIT (small tiles, see SplitK): the lane runs only samples [sk.sBegin, sk.sEnd) of its pixel and hands per-sample radiance
 // and its last reservoir to split_resolve_pixel instead of accumulating and storing itself.
 struct SplitK {
-    hrt_float3* li;          // [spp][nPix]: SafeColor(Li) of every sample
-    float* stage;            // [nGroups][12][nPix]: L.xyz wi.xyz pdf w wSum m lightId flag of the group's last reservoir
+    hrt_float3* li;          // [spp][nLocal]: SafeColor(Li) of every sample
+    float* stage;            // [nGroups][12][nLocal]: L.xyz wi.xyz pdf w wSum m lightId flag of the group's last reservoir
     int sBegin, sEnd, group, nGroups;
+    int local, nLocal;       // this lane's slot in the scratch planes and their length: lanes of the launch's tiles, not image pixels
 };
 template <class TR, bool COUNT, bool SPLIT = false>
 HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb,
@@ -849,7 +850,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     const int spp = SPLIT ? sk->sEnd : sppAll;           // end of this lane's sample range
     F3 Lframe = mk3(0.f, 0.f, 0.f);
     auto add_sample = [&](int sIdx, F3 c) {              // Lframe += SafeColor(Li), RTRay.cs:320 -- or hand the term to the resolve
-        if (SPLIT) sk->li[(size_t)sIdx * (size_t)nPix + (size_t)index] = to3(c);
+        if (SPLIT) sk->li[(size_t)sIdx * (size_t)sk->nLocal + (size_t)sk->local] = to3(c);
         else Lframe = Lframe + c;
     };
 
@@ -859,7 +860,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     {
         F3 c = safe_color(sky(k, primary_ray(k, px, py).d));
         for (int s = sFirst; s < spp; s++) add_sample(s, c);     // :214-219, same value every sample
-        if (SPLIT) sk->stage[(size_t)sk->group * 12 * (size_t)nPix + 11 * (size_t)nPix + (size_t)index] = 0.f;      // no reservoir from this group
+        if (SPLIT) sk->stage[((size_t)sk->group * 12 + 11) * (size_t)sk->nLocal + (size_t)sk->local] = 0.f;      // no reservoir from this group
     }
     else
     {
@@ -1010,8 +1011,8 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         }
         if (SPLIT)
         {   // this group's last reservoir (or "none"): split_resolve_pixel keeps the one of the last group that has one
-            float* st = sk->stage + (size_t)sk->group * 12 * (size_t)nPix + (size_t)index;
-            const size_t P = (size_t)nPix;
+            float* st = sk->stage + (size_t)sk->group * 12 * (size_t)sk->nLocal + (size_t)sk->local;
+            const size_t P = (size_t)sk->nLocal;
             st[11 * P] = haveRes ? 1.f : 0.f;
             if (haveRes)
             {
@@ -1036,16 +1037,16 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
 }
 
 // second half of a SPLIT frame: ordered sample sum (:320-324), reservoir of the last sample that reached a diffuse vertex
-HRT_D void split_resolve_pixel(const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb, const DReservoir& resCur, int64_t nPix, int index,
-                               const hrt_float3* li, const float* stage, int nGroups)
+HRT_D void split_resolve_pixel(const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb, const DReservoir& resCur, int index,
+                               const hrt_float3* li, const float* stage, int nGroups, int local, int nLocal)
 {
     const int spp = hrt_imax(1, k.spp);
     F3 Lframe = mk3(0.f, 0.f, 0.f);
-    for (int s = 0; s < spp; s++) Lframe = Lframe + ld3(&li[(size_t)s * (size_t)nPix + (size_t)index]);
-    const size_t P = (size_t)nPix;
+    for (int s = 0; s < spp; s++) Lframe = Lframe + ld3(&li[(size_t)s * (size_t)nLocal + (size_t)local]);
+    const size_t P = (size_t)nLocal;
     for (int g = nGroups - 1; g >= 0; g--)
     {
-        const float* st = stage + (size_t)g * 12 * P + (size_t)index;
+        const float* st = stage + (size_t)g * 12 * P + (size_t)local;
         if (st[11 * P] != 0.f)
         {
             resCur.L[index] = to3(mk3(st[0], st[P], st[2 * P])); resCur.wi[index] = to3(mk3(st[3 * P], st[4 * P], st[5 * P]));

@@ -12,7 +12,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <functional>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
@@ -22,6 +24,7 @@
 #include "../../include/hip_raytrace.h"
 
 using namespace hrt;
+
 
 // ---------------------------------------------------------------------------------------
 // Pixel <-> lane mapping.  A 256-thread workgroup shades a 32x8 pixel tile: each of its 4
@@ -90,15 +93,18 @@ hrt_path_trace_split_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DRese
     SplitK sk;
     sk.li = li; sk.stage = stage; sk.group = g; sk.nGroups = nGroups;
     sk.sBegin = g * perGroup; sk.sEnd = min(sk.sBegin + perGroup, max(1, k.spp));
+    const int tileBlock = blockIdx.x - g * tm.nTiles;
+    sk.local = tileBlock * (int)blockDim.x + (int)threadIdx.x; sk.nLocal = tm.nTiles * (int)blockDim.x;
     int x, y;
-    if (tile_pixel(tm, k, x, y, blockIdx.x - g * tm.nTiles)) path_trace_pixel<TR, false, true>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C, &sk);
+    if (tile_pixel(tm, k, x, y, tileBlock)) path_trace_pixel<TR, false, true>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C, &sk);
 }
 
 __global__ void __launch_bounds__(256)
 hrt_split_resolve_kernel(FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resCur, long long nPix, TileMap tm, const hrt_float3* li, const float* stage, int nGroups)
 {
     int x, y;
-    if (tile_pixel(tm, k, x, y, blockIdx.x)) split_resolve_pixel(k, gb, fb, resCur, nPix, y * k.width + x, li, stage, nGroups);
+    if (tile_pixel(tm, k, x, y, blockIdx.x)) split_resolve_pixel(k, gb, fb, resCur, y * k.width + x, li, stage, nGroups,
+                                                                 (int)(blockIdx.x * blockDim.x + threadIdx.x), tm.nTiles * (int)blockDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -192,6 +198,7 @@ hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int c
     C.flush(counters);
 }
 
+#ifdef HRT_TUNING
 template <int FEAT>
 __global__ void __launch_bounds__(256, 4)
 hrt_wf_walkw_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained)
@@ -209,6 +216,7 @@ hrt_wf_walkw_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int 
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
     wf_walkw_closest_wave<FEAT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own);
 }
+#endif
 
 template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256)
@@ -293,6 +301,7 @@ struct DeviceState {
     hipEvent_t ev[kRing][4] = {};
     int ring_head = 0;                         // frames enqueued since the last synchronize
     bool ring_counts = false;
+    std::vector<float> frame_ms[2];            // per-frame HIP-event times (launch 1, path-trace stage) of the frames the last hrt_synchronize collected
     // scene (15 arrays)
     void* scene[15] = {};
     DScene dscene{};
@@ -350,6 +359,8 @@ struct hrt_ctx {
     int64_t n_positions = 0, n_spheres = 0;
     int64_t scene_count[15] = {};
     int width = 0, height = 0;
+    long long max_resident_paths = 0;          // hrt_set_workspace_limit: 0 = kWfMaxPaths
+    std::vector<std::pair<char*, size_t>> pinned;   // hrt_host_register: page-locked ranges of the caller (gather targets)
 };
 
 namespace {
@@ -362,6 +373,19 @@ int fail(hrt_ctx* c, int code, const std::string& msg)
 {
     if (c) c->err = msg; else g_create_error = msg;
     return code;
+}
+
+// no exception crosses the C ABI: std::bad_alloc of the host-side vectors / strings -> HRT_ERR_OUT_OF_MEMORY, anything else -> HRT_ERR_HIP
+int on_exception(hrt_ctx* c, const char* who) noexcept
+{
+    try
+    {
+        try { throw; }
+        catch (const std::bad_alloc&) { return fail(c, HRT_ERR_OUT_OF_MEMORY, std::string(who) + ": out of host memory"); }
+        catch (const std::exception& e) { return fail(c, HRT_ERR_HIP, std::string(who) + ": " + e.what()); }
+        catch (...) { return fail(c, HRT_ERR_HIP, std::string(who) + ": unknown exception"); }
+    }
+    catch (...) { return HRT_ERR_OUT_OF_MEMORY; }      // not even the message could be stored
 }
 
 #define HIPCHK(ctx, expr)                                                                          \
@@ -579,7 +603,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     // walk visits the same nodes in the same order.  perm[old - lo] = new - lo.
     auto walk_order = [&](const hrt_bvh_node* src, int64_t lo, int64_t hi, int64_t root, std::vector<int32_t>& perm) -> int32_t {   // returns the number of reachable nodes
         const size_t n = (size_t)(hi - lo);
-        if (getenv("HRT_BUILDER_ORDER")) { perm.resize(n); for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i; return -1; }   // A/B knob
+        if (HRT_ENV("HRT_BUILDER_ORDER")) { perm.resize(n); for (size_t i = 0; i < n; i++) perm[i] = (int32_t)i; return -1; }   // A/B knob
         perm.assign(n, -1);
         int32_t next = 0;
         std::vector<int64_t> st;
@@ -846,7 +870,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         return rootWide;
     };
     out.wide.clear();
-    if (out.ok && reachableT > 0 && getenv("HRT_WIDE") && atoi(getenv("HRT_WIDE")) > 0)        // experiment, off by default
+    if (out.ok && reachableT > 0 && HRT_ENV("HRT_WIDE") && atoi(HRT_ENV("HRT_WIDE")) > 0)        // experiment, off by default
     {
         int dT = 0;
         out.wide_tlas_root = collapse(out.tlas, 0, dT);
@@ -880,7 +904,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     // one record per instance holding the box of its one-node BLAS; the walker treats them as nodes (count field 15), so the
     // instance box tests ride the node steps and their lookahead instead of costing a leaf step each.
     out.tlasX.assign(1, NodeQ{});
-    if (out.ok && out.feat == 0 && reachableT > 0 && nT + nTI < kEnd && !getenv("HRT_NO_INLINE_INSTANCES"))
+    if (out.ok && out.feat == 0 && reachableT > 0 && nT + nTI < kEnd && !HRT_ENV("HRT_NO_INLINE_INSTANCES"))
     {
         std::vector<int32_t> nidx((size_t)nT);
         int32_t at = 0;
@@ -1011,7 +1035,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     {
         const dim3 grid(tm.nTiles), block(64 * tm.wpb);
         // sample groups when the tile gives the machine less than ~5 rounds of waves
-        static const int splitEnv = getenv("HRT_SPLIT") ? atoi(getenv("HRT_SPLIT")) : -1;          // A/B knob: 0 never, n > 0 force n groups
+        static const int splitEnv = HRT_ENV("HRT_SPLIT") ? atoi(HRT_ENV("HRT_SPLIT")) : -1;          // A/B knob: 0 never, n > 0 force n groups
         const int sppN = k.spp > 1 ? k.spp : 1;
         const long long waves = (long long)tm.nTiles * tm.wpb, slots = (long long)d.n_cu * 4 * HRT_PT_WAVES;
         int nGroups = 1;
@@ -1024,7 +1048,9 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         {
             const int perGroup = (sppN + nGroups - 1) / nGroups;
             nGroups = (sppN + perGroup - 1) / perGroup;
-            const size_t need = ((size_t)sppN * 3 + (size_t)nGroups * 12) * (size_t)nPix;
+            // scratch planes over the lanes of THIS launch's tiles (a rank's share of the frame), not over the image
+            const size_t nLocal = (size_t)tm.nTiles * 64 * (size_t)tm.wpb;
+            const size_t need = ((size_t)sppN * 3 + (size_t)nGroups * 12) * nLocal;
             if (need > d.split_floats)
             {
                 if (d.split_mem) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.split_mem); d.split_mem = nullptr; d.split_floats = 0; }
@@ -1033,7 +1059,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 d.split_mem = (float*)v; d.split_floats = need;
             }
             hrt_float3* li = (hrt_float3*)d.split_mem;
-            float* stage = d.split_mem + (size_t)sppN * 3 * (size_t)nPix;
+            float* stage = d.split_mem + (size_t)sppN * 3 * nLocal;
             hipLaunchKernelGGL((hrt_path_trace_split_kernel<TR>), dim3(tm.nTiles * nGroups), block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, li, stage, nGroups, perGroup);
             hipLaunchKernelGGL(hrt_split_resolve_kernel, grid, block, 0, d.stream, k, d.gb, d.fb, resCur, nPix, tm, (const hrt_float3*)li, (const float*)stage, nGroups);
             HIPCHK(c, hipGetLastError());
@@ -1049,7 +1075,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     g.nOrd = g.tilesX8 * d.n_strips * 64;
     const int spp = k.spp > 1 ? k.spp : 1;
     long long maxPaths = kWfMaxPaths;
-    if (const char* e = getenv("HRT_WF_MAX_PATHS")) { long long v = atoll(e); if (v > 0) maxPaths = v; }   // test knob: forces several sample batches
+    if (c->max_resident_paths > 0) maxPaths = c->max_resident_paths;              // hrt_set_workspace_limit
     long long sb = maxPaths / g.nOrd;
     if (sb < 1) sb = 1;
     if (sb > spp) sb = spp;
@@ -1064,9 +1090,10 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
     // wide walker (experiment, HRT_WIDE=1 at upload and render time; production frames only): needs the collapsed trees and a
     // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
-    static const int wideEnv = getenv("HRT_WIDE") ? atoi(getenv("HRT_WIDE")) : 0;
-    static const bool forkShadow = getenv("HRT_NO_FORK") == nullptr;       // A/B knob
-    static const bool forkStatic = getenv("HRT_FORK_STATIC") != nullptr;   // A/B knob
+    static const int wideEnv = HRT_ENV("HRT_WIDE") ? atoi(HRT_ENV("HRT_WIDE")) : 0;
+    static const bool forkShadow = HRT_ENV("HRT_NO_FORK") == nullptr;       // A/B knob
+    static const bool forkStatic = HRT_ENV("HRT_FORK_STATIC") != nullptr;   // A/B knob
+#ifdef HRT_TUNING
     const bool wide = wideEnv > 0 && !count && PackedFeat<TR>::value >= 0 && c->wide_depth > 0 && c->wide_depth <= kWideMaxDepth;
     if (wide && !d.wf_ovf)
     {
@@ -1074,6 +1101,10 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         HIPCHK(c, hipMalloc(&v, (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));
         d.wf_ovf = (int*)v; W.ovf = d.wf_ovf;
     }
+#else
+    constexpr bool wide = false;
+    (void)wideEnv;
+#endif
     for (int b0 = 0; b0 < spp; b0 += (int)sb)
     {
         if (k.maxDepth > 0) HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
@@ -1097,12 +1128,14 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
+#ifdef HRT_TUNING
                 else if (wide)
                 {
                     hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained);
                     hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
+#endif
                 else if ((chained || forkStatic) && forkShadow)
                 {   // the two walks of a bounce are independent (shadow requests vs bounce rays) and both are persistent
                     // launches that end in a drain: on two streams the second one's workgroups move into the wave slots
@@ -1146,19 +1179,27 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
 
 extern "C" {
 
-const char* hrt_version(void) { return "hip_raytrace 0.2 (gfx950)"; }
+const char* hrt_version(void)
+{
+#ifdef HRT_TUNING
+    return "hip_raytrace 0.3 (gfx950) tuning-build";
+#else
+    return "hip_raytrace 0.3 (gfx950)";
+#endif
+}
 
 int hrt_device_count(void)
-{
+try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
     return n;
 }
+catch (...) { return on_exception(nullptr, "hrt_device_count"); }
 
 const char* hrt_last_error(hrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
-{
+try {
     if (!out) return fail(nullptr, HRT_ERR_INVALID_ARG, "hrt_create: out is NULL");
     *out = nullptr;
     int avail = 0;
@@ -1203,10 +1244,14 @@ int hrt_create(const int* device_ids, int n_dev, hrt_ctx** out)
     *out = c;
     return HRT_OK;
 }
+catch (...) { return on_exception(nullptr, "hrt_create"); }
 
 void hrt_destroy(hrt_ctx* c)
 {
     if (!c) return;
+    for (DeviceState& d : c->dev) if (d.device_id >= 0 && d.stream) { (void)hipSetDevice(d.device_id); (void)hipStreamSynchronize(d.stream); }
+    for (const auto& r : c->pinned) (void)hipHostUnregister(r.first);
+    c->pinned.clear();
     for (DeviceState& d : c->dev)
     {
         if (d.device_id < 0) continue;
@@ -1228,7 +1273,7 @@ void hrt_destroy(hrt_ctx* c)
 }
 
 int hrt_synchronize(hrt_ctx* c, hrt_stats* stats)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     hrt_stats st; std::memset(&st, 0, sizeof(st));
     st.n_devices = (int)c->dev.size();
@@ -1237,11 +1282,12 @@ int hrt_synchronize(hrt_ctx* c, hrt_stats* stats)
         HIPCHK(c, hipSetDevice(d.device_id));
         HIPCHK(c, hipStreamSynchronize(d.stream));        // _cuda.Synchronize(), RTRenderer.cs:233
         double k0 = 0, k1 = 0, dh = 0;
+        if (d.ring_head > 0) { d.frame_ms[0].clear(); d.frame_ms[1].clear(); }
         for (int f = 0; f < d.ring_head; f++)
         {
             float ms;
-            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][0], d.ev[f][1])); k0 += ms;
-            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][1], d.ev[f][2])); k1 += ms;
+            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][0], d.ev[f][1])); k0 += ms; d.frame_ms[0].push_back(ms);
+            HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][1], d.ev[f][2])); k1 += ms; d.frame_ms[1].push_back(ms);
             HIPCHK(c, hipEventElapsedTime(&ms, d.ev[f][2], d.ev[f][3])); dh += ms;
         }
         st.kernel_ms[0] = std::max(st.kernel_ms[0], k0);
@@ -1265,9 +1311,10 @@ int hrt_synchronize(hrt_ctx* c, hrt_stats* stats)
     if (stats) *stats = st;
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_synchronize"); }
 
 int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!s) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_upload: scene is NULL");
     const void* src[15] = {s->tlasNodes, s->tlasInstanceIndices, s->instances, s->blasNodes, s->spherePrimIdx, s->spheres,
@@ -1360,7 +1407,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
             T.tlas = (NodeQ*)d.packed[0]; T.finst = (FInst*)d.packed[1]; T.tlasX = (NodeQ*)d.packed[6]; T.flat = (NodeQ*)d.packed[4];
             T.parent = (int*)d.tlaux[0]; T.nchild = (int*)d.tlaux[1]; T.arrive = (int*)d.tlaux[2]; T.scanIn = (unsigned long long*)d.tlaux[3]; T.scanOut = (unsigned long long*)d.tlaux[4];
             T.scanTmp = d.tlaux[9]; T.scanTmpBytes = scanTmp; T.costPartial = (float*)((char*)d.tlaux[9] + scanTmp);
-            T.directMax = (ph.refit_ok && !getenv("HRT_BUILDER_ORDER")) ? 63 : 1;
+            T.directMax = (ph.refit_ok && !HRT_ENV("HRT_BUILDER_ORDER")) ? 63 : 1;
             T.sa = (float*)d.tlaux[5]; T.flags = (int*)d.tlaux[6]; T.cost = (float*)d.tlaux[7]; T.saBase = (float*)d.tlaux[8];
             T.nI = (int)s->n_instances; T.nT = (int)s->n_tlasNodes; T.nTI = (int)s->n_tlasInstanceIndices;
             if ((!ph.meshInst.empty() || !ph.sphereInst.empty()) && ph.blas_refit_ok)
@@ -1403,6 +1450,7 @@ int hrt_scene_upload(hrt_ctx* c, const hrt_scene_desc* s)
     c->scene_ready = true;
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_scene_upload"); }
 
 namespace {
 
@@ -1478,6 +1526,10 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             if ((rc = keep_as_base()) != HRT_OK) return rc;
         }
         std::vector<void*> staged;
+        struct StagedGuard {               // staging buffers of `mutate` are freed on every way out (their copies are ordered on d.stream)
+            std::vector<void*>& v; hipStream_t st;
+            ~StagedGuard() { if (!v.empty()) { (void)hipStreamSynchronize(st); for (void* p : v) (void)hipFree(p); } }
+        } stagedGuard{staged, d.stream};
         if ((rc = mutate(d, staged)) != HRT_OK) return rc;
         int action = policy == HRT_REBUILD_FORCE_REBUILD ? HRT_REBUILD_FORCE_REBUILD : HRT_REBUILD_FORCE_REFIT;
         if (policy == HRT_REBUILD_AUTO && !d.tlas_lbvh) action = HRT_REBUILD_FORCE_REBUILD;   // an uploaded tree: the device-built one costs as much as a refit and walks faster
@@ -1501,12 +1553,13 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         }
         HIPCHK(c, hipEventRecord(e1, d.stream));
         HIPCHK(c, hipEventSynchronize(e1));
-        for (void* p : staged) HIPCHK(c, hipFree(p));
+        for (void* p : staged) (void)hipFree(p);
+        staged.clear();
         // the walkers' view of the tree
         const bool general = h_flags[0] != 0;
         d.dpacked.nTlas = T.nT;
-        const bool walkOrder = action == HRT_REBUILD_FORCE_REBUILD || c->tlas_on_device || !getenv("HRT_BUILDER_ORDER");
-        const bool inl = !general && !c->feat_alpha && walkOrder && (int64_t)T.nT + T.nTI < kEnd && !getenv("HRT_NO_INLINE_INSTANCES");
+        const bool walkOrder = action == HRT_REBUILD_FORCE_REBUILD || c->tlas_on_device || !HRT_ENV("HRT_BUILDER_ORDER");
+        const bool inl = !general && !c->feat_alpha && walkOrder && (int64_t)T.nT + T.nTI < kEnd && !HRT_ENV("HRT_NO_INLINE_INSTANCES");
         d.dpacked.tlasX = inl ? (const NodeQ*)d.packed[6] : nullptr;
         d.dpacked.nTlasX = inl ? T.nT + T.nTI : 0;
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = kWNone;
@@ -1533,7 +1586,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
 } // namespace
 
 int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const hrt_affine3x4* xf, int32_t policy, hrt_bvh_update_stats* st)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_instances: no scene uploaded");
     if (n < 0 || (n > 0 && (!ids || !xf))) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_update_instances: n instances need ids and transforms");
@@ -1557,9 +1610,10 @@ int hrt_scene_update_instances(hrt_ctx* c, const int32_t* ids, int32_t n, const 
         return HRT_OK;
     }, st);
 }
+catch (...) { return on_exception(c, "hrt_scene_update_instances"); }
 
 int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_float3* positions, int32_t policy, hrt_bvh_update_stats* st)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_positions: no scene uploaded");
     if (first < 0 || n < 0 || first + n > c->n_positions || (n > 0 && !positions))
@@ -1615,9 +1669,10 @@ int hrt_scene_update_positions(hrt_ctx* c, int64_t first, int64_t n, const hrt_f
     if (rc == HRT_OK && st) { st->blas_action = blasAction; st->blas_growth = blasGrowth; }
     return rc;
 }
+catch (...) { return on_exception(c, "hrt_scene_update_positions"); }
 
 int hrt_scene_update_spheres(hrt_ctx* c, int64_t first, int64_t n, const hrt_sphere* spheres, int32_t policy, hrt_bvh_update_stats* st)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_update_spheres: no scene uploaded");
     if (first < 0 || n < 0 || first + n > c->n_spheres || (n > 0 && !spheres))
@@ -1631,9 +1686,10 @@ int hrt_scene_update_spheres(hrt_ctx* c, int64_t first, int64_t n, const hrt_sph
         return HRT_OK;
     }, st);
 }
+catch (...) { return on_exception(c, "hrt_scene_update_spheres"); }
 
 int hrt_scene_download_array(hrt_ctx* c, int dev, int array, void* dst, int64_t cap, int64_t* count)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_download_array: no scene uploaded");
     if (dev < 0 || dev >= (int)c->dev.size() || array < 0 || array >= 15) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_array: device slot or array index out of range");
@@ -1649,9 +1705,10 @@ int hrt_scene_download_array(hrt_ctx* c, int dev, int array, void* dst, int64_t 
     HIPCHK(c, hipStreamSynchronize(d.stream));
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_scene_download_array"); }
 
 int hrt_scene_download_tlas(hrt_ctx* c, int dev, hrt_bvh_node* nodes, int64_t capN, int32_t* idx, int64_t capI, hrt_instance* inst, int64_t capInst, int64_t* counts)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_scene_download_tlas: no scene uploaded");
     if (dev < 0 || dev >= (int)c->dev.size()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_scene_download_tlas: device slot out of range");
@@ -1669,9 +1726,10 @@ int hrt_scene_download_tlas(hrt_ctx* c, int dev, hrt_bvh_node* nodes, int64_t ca
     HIPCHK(c, hipStreamSynchronize(d.stream));
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_scene_download_tlas"); }
 
 int hrt_reset_history(hrt_ctx* c)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     int rc = hrt_synchronize(c, nullptr);
     if (rc != HRT_OK) return rc;
@@ -1692,9 +1750,10 @@ int hrt_reset_history(hrt_ctx* c)
     }
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_reset_history"); }
 
 int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opts* opts, const hrt_outputs* out, hrt_stats* stats)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!p) return fail(c, HRT_ERR_INVALID_ARG, "hrt_render_frame: params is NULL");
     if (!c->scene_ready) return fail(c, HRT_ERR_INVALID_STATE, "hrt_render_frame: no scene uploaded (call hrt_scene_upload first)");
@@ -1760,7 +1819,7 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     };
     // pixel kernels: waves per workgroup.  One wave per workgroup gives the dispatcher the finest grain: the launch ends when
     // the last 8x8 tile ends instead of the last 32x8 tile (matters most when a rank renders 1/8 of the image)
-    static const int ptWaves = getenv("HRT_PT_BLOCK") ? std::max(1, std::min(4, atoi(getenv("HRT_PT_BLOCK")) / 64)) : 4;
+    static const int ptWaves = HRT_ENV("HRT_PT_BLOCK") ? std::max(1, std::min(4, atoi(HRT_ENV("HRT_PT_BLOCK")) / 64)) : 4;
     auto tile_map = [&](const DeviceState& d) {
         TileMap tm;
         tm.wpb = ptWaves;
@@ -1774,7 +1833,7 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
     const int variant = usePacked ? c->packed_feat : -1;
     const bool mega = (flags & HRT_FLAG_MEGAKERNEL) ? true : ((flags & HRT_FLAG_STREAMED) ? false : c->small_scene);
     // production frames of a tiny fast-sphere scene in the fused kernel: wave-uniform sweep over the TLAS leaves
-    static const bool noFlat = getenv("HRT_NO_FLAT") != nullptr;       // A/B knob
+    static const bool noFlat = HRT_ENV("HRT_NO_FLAT") != nullptr;       // A/B knob
     const bool flat = variant == 0 && mega && !count && c->flat_leaves > 0 && !noFlat;
     auto with_tracer = [&](DeviceState& d, auto fn) -> int {
         if (flat) { TracerFlat t; t.tree.P = d.dpacked; t.tree.S = d.dscene; t.leaves = (const NodeQ*)d.packed[4]; t.nLeaves = c->flat_leaves; return fn(t); }
@@ -1873,15 +1932,17 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
         });
         if (rc != HRT_OK) return rc;
     }
-    for (DeviceState& d : c->dev)
-    {
-        HIPCHK(c, hipSetDevice(d.device_id));
+    // ---- phase 3: per-tile gather into the caller's host framebuffer.  Each device's copies are issued by its own host
+    // thread when the ctx spans several devices: a copy into pageable memory blocks its issuing thread, so one thread
+    // would serialise the N gathers.  Into page-locked memory (hrt_host_register) the copies are asynchronous DMA anyway.
+    auto gather_device = [&](DeviceState& d, hrt_ctx* ec) -> int {        // ec == nullptr: errors go to the calling thread's own slot
+        HIPCHK(ec, hipSetDevice(d.device_id));
         DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
         if (out)
-        {   // per-tile gather into the caller's host framebuffer
+        {
             int rc;
-#define G(hostp, devp) if ((rc = gather_rows(c, d, hostp, devp, W)) != HRT_OK) return rc
+#define G(hostp, devp) if ((rc = gather_rows(ec, d, hostp, devp, W)) != HRT_OK) return rc
             G(out->color, d.fb.color); G(out->depth, d.fb.depth); G(out->objectId, d.fb.objectId);
             G(out->radiance, d.fb.radiance);
             G(out->gb_worldPos, d.gb.worldPos); G(out->gb_normalWS, d.gb.normalWS); G(out->gb_baseColor, d.gb.baseColor);
@@ -1890,17 +1951,34 @@ int hrt_render_frame(hrt_ctx* c, const hrt_frame_params* p, const hrt_render_opt
             G(out->res_wSum, resCur.wSum); G(out->res_m, resCur.m); G(out->res_lightId, resCur.lightId);
 #undef G
             if (out->cameraId && d.row_begin == 0 && d.strip_i == 0 && d.n_strips > 0)
-                HIPCHK(c, hipMemcpyAsync(out->cameraId, d.fb.cameraId, 4, hipMemcpyDeviceToHost, d.stream));
+                HIPCHK(ec, hipMemcpyAsync(out->cameraId, d.fb.cameraId, 4, hipMemcpyDeviceToHost, d.stream));
         }
-        HIPCHK(c, hipEventRecord(ev[3], d.stream));
-        d.ring_head++;
+        HIPCHK(ec, hipEventRecord(ev[3], d.stream));
+        return HRT_OK;
+    };
+    if (out && nd > 1)
+    {
+        std::vector<int> rcs((size_t)nd, HRT_OK);
+        std::vector<std::string> errs((size_t)nd);
+        std::vector<std::thread> workers;
+        for (int i = 0; i < nd; i++)
+            workers.emplace_back([&, i]() {
+                try { rcs[(size_t)i] = gather_device(c->dev[(size_t)i], nullptr); if (rcs[(size_t)i] != HRT_OK) errs[(size_t)i] = g_create_error; }
+                catch (...) { rcs[(size_t)i] = HRT_ERR_OUT_OF_MEMORY; }
+            });
+        for (std::thread& t : workers) t.join();
+        for (int i = 0; i < nd; i++) if (rcs[(size_t)i] != HRT_OK) return fail(c, rcs[(size_t)i], "hrt_render_frame: gather of device slot " + std::to_string(i) + ": " + errs[(size_t)i]);
     }
+    else
+        for (DeviceState& d : c->dev) { int rc = gather_device(d, c); if (rc != HRT_OK) return rc; }
+    for (DeviceState& d : c->dev) d.ring_head++;
     if (nosync) { if (stats) std::memset(stats, 0, sizeof(*stats)); return HRT_OK; }
     return hrt_synchronize(c, stats);
 }
+catch (...) { return on_exception(c, "hrt_render_frame"); }
 
 int hrt_present(hrt_ctx* c, const hrt_present_params* pp, int32_t* out_color_host)
-{
+try {
     if (!c) return HRT_ERR_INVALID_ARG;
     if (!pp) return fail(c, HRT_ERR_INVALID_ARG, "hrt_present: params is NULL");
     if (pp->out_width <= 0 || pp->out_height <= 0 || (int64_t)pp->out_width * pp->out_height > 0x7FFFFFFFLL)
@@ -1953,9 +2031,58 @@ int hrt_present(hrt_ctx* c, const hrt_present_params* pp, int32_t* out_color_hos
     HIPCHK(c, hipStreamSynchronize(d.stream));
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_present"); }
+
+int hrt_set_workspace_limit(hrt_ctx* c, int64_t max_resident_paths)
+try {
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (max_resident_paths < 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_set_workspace_limit: the limit must be >= 0 (0 = default)");
+    c->max_resident_paths = max_resident_paths;
+    return HRT_OK;
+}
+catch (...) { return on_exception(c, "hrt_set_workspace_limit"); }
+
+int hrt_host_register(hrt_ctx* c, void* ptr, int64_t bytes)
+try {
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (!ptr || bytes <= 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_host_register: needs a pointer and a positive size");
+    for (const auto& r : c->pinned) if (r.first == (char*)ptr) return fail(c, HRT_ERR_INVALID_STATE, "hrt_host_register: this range is registered already");
+    HIPCHK(c, hipSetDevice(c->dev[0].device_id));
+    HIPCHK(c, hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable));
+    c->pinned.emplace_back((char*)ptr, (size_t)bytes);
+    return HRT_OK;
+}
+catch (...) { return on_exception(c, "hrt_host_register"); }
+
+int hrt_host_unregister(hrt_ctx* c, void* ptr)
+try {
+    if (!c) return HRT_ERR_INVALID_ARG;
+    for (size_t i = 0; i < c->pinned.size(); i++)
+        if (c->pinned[i].first == (char*)ptr)
+        {
+            int rc = hrt_synchronize(c, nullptr);                 // no copy into the range may still be in flight
+            if (rc != HRT_OK) return rc;
+            c->pinned.erase(c->pinned.begin() + (long)i);
+            HIPCHK(c, hipHostUnregister(ptr));
+            return HRT_OK;
+        }
+    return fail(c, HRT_ERR_INVALID_ARG, "hrt_host_unregister: range was not registered through this context");
+}
+catch (...) { return on_exception(c, "hrt_host_unregister"); }
+
+int hrt_frame_times(hrt_ctx* c, int dev, int launch, float* ms, int cap, int* n)
+try {
+    if (!c) return HRT_ERR_INVALID_ARG;
+    if (dev < 0 || dev >= (int)c->dev.size() || launch < 0 || launch > 1 || cap < 0) return fail(c, HRT_ERR_INVALID_ARG, "hrt_frame_times: device slot or launch out of range");
+    const std::vector<float>& v = c->dev[(size_t)dev].frame_ms[launch];
+    if (n) *n = (int)v.size();
+    if (ms) for (int i = 0; i < cap && i < (int)v.size(); i++) ms[i] = v[(size_t)i];
+    return HRT_OK;
+}
+catch (...) { return on_exception(c, "hrt_frame_times"); }
 
 int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
-{
+try {
     if (!c || !o) return HRT_ERR_INVALID_ARG;
     if (dev < 0 || dev >= (int)c->dev.size()) return fail(c, HRT_ERR_INVALID_ARG, "hrt_device_buffers: device slot out of range");
     DeviceState& d = c->dev[dev];
@@ -1975,10 +2102,11 @@ int hrt_device_buffers(hrt_ctx* c, int dev, hrt_device_views* o)
     }
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_device_buffers"); }
 
 // test hook: evaluate hrt_math.h function `fn` on device 0 of ctx (see hrt_math_probe_kernel)
 int hrt_math_probe(hrt_ctx* c, int fn, int n, const float* x, const float* y, float* out)
-{
+try {
     if (!c || !x || !out || n <= 0) return HRT_ERR_INVALID_ARG;
     DeviceState& d = c->dev[0];
     HIPCHK(c, hipSetDevice(d.device_id));
@@ -1994,6 +2122,7 @@ int hrt_math_probe(hrt_ctx* c, int fn, int n, const float* x, const float* y, fl
     (void)hipFree(dx); (void)hipFree(dout); if (dy) (void)hipFree(dy);
     return HRT_OK;
 }
+catch (...) { return on_exception(c, "hrt_math_probe"); }
 
 } // extern "C"
 

@@ -94,6 +94,18 @@ struct RayPark {
     }
 };
 HRT_D F3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
+// TransformPoint / TransformVector (SceneDeviceViews.cs:483-493) with the identity matrix, evaluated literally:
+// ((1*x + 0*y) + 0*z) (+ 0) is x for x != 0 but decides the SIGN of a zero result.  The walks skip the transform of identity
+// instances (no comparison, division guard or t of the walk can see a zero's sign); the winner's shading, whose normal is
+// stored, applies it, so every output stays bit-for-bit what the reference's statement order produces.
+HRT_D F3 ident_point(F3 p)
+{
+    return mk3(((1.f * p.x + 0.f * p.y) + 0.f * p.z) + 0.f, ((0.f * p.x + 1.f * p.y) + 0.f * p.z) + 0.f, ((0.f * p.x + 0.f * p.y) + 1.f * p.z) + 0.f);
+}
+HRT_D F3 ident_vector(F3 v)
+{
+    return mk3((1.f * v.x + 0.f * v.y) + 0.f * v.z, (0.f * v.x + 1.f * v.y) + 0.f * v.z, (0.f * v.x + 0.f * v.y) + 1.f * v.z);
+}
 HRT_D int wbits(float4 v) { return __float_as_int(v.w); }
 
 // FEAT bit 0: the scene has leaf slots that are not fast spheres (general walkers compiled in)
@@ -117,6 +129,15 @@ struct TracerPackedT {
         r.d = xform_vector(inst->worldToObject, w.d);
         r.inv = inv_dir(r.d);
         return r;
+    }
+
+    // the object-space ray the winner is shaded with: as object_ray, but an identity transform is evaluated literally
+    // (origin and direction only: shading never reads 1/d)
+    static HRT_D Ray ident_ray(const Ray& w) { Ray r; r.o = ident_point(w.o); r.d = ident_vector(w.d); r.inv = w.inv; return r; }
+    HRT_D Ray shading_ray(const Ray& w, int flags, int instIdx) const
+    {
+        if (flags & FI_IDENTITY) return ident_ray(w);
+        return object_ray(w, flags, instIdx);
     }
 
     // UV + texture path of one triangle hit (SceneDeviceViews.cs:201-218 / :297-315)
@@ -310,7 +331,7 @@ struct TracerPackedT {
         F3 nObj;
         if (!kGeneral || (flags & (FI_FAST_SPHERE | FI_SPHERESET)))
         {
-            Ray iray = (!kGeneral || (flags & FI_FAST_SPHERE)) ? wray : object_ray(wray, flags, wbits(f.b));
+            Ray iray = (!kGeneral || (flags & FI_FAST_SPHERE)) ? ident_ray(wray) : shading_ray(wray, flags, wbits(f.b));
             const hrt_sphere* sp = &S.spheres[bestPrim];
             nObj = sphere_normal(iray, cv3(sp->center), bestTObj);
             F3 kd = cv3(sp->material.Kd);
@@ -330,7 +351,7 @@ struct TracerPackedT {
         }
         else
         {
-            Ray iray = object_ray(wray, flags, wbits(f.b));
+            Ray iray = shading_ray(wray, flags, wbits(f.b));
             FTri tr = P.ftri[bestPrim];
             F3 v0 = xyz(tr.v0), v1 = xyz(tr.v1), v2 = xyz(tr.v2);
             nObj = normalize(cross(v1 - v0, v2 - v0));
@@ -352,7 +373,7 @@ struct TracerPackedT {
             best.albedo = kd;
             best.objId = wbits(tr.v0);
         }
-        if (!kGeneral || (flags & FI_IDENTITY)) best.n = normalize(nObj);   // objectToWorld = I: n*1 + 0 + 0
+        if (!kGeneral || (flags & FI_IDENTITY)) best.n = normalize(ident_vector(nObj));   // objectToWorld = I, evaluated literally (zero signs)
         else best.n = normalize(xform_vector(S.instances[wbits(f.b)].objectToWorld, nObj));
         return true;
     }

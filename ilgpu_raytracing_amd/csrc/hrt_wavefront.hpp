@@ -34,7 +34,9 @@
 #pragma once
 #include "hrt_device.hpp"
 #include "hrt_walker.hpp"
-#include "hrt_walker_wide.hpp"
+#ifdef HRT_TUNING
+#include "hrt_walker_wide.hpp"          // experimental 4-wide walker: measured slower, tuning builds only
+#endif
 
 namespace hrt {
 
@@ -461,6 +463,7 @@ HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& 
         }, C);
 }
 
+#ifdef HRT_TUNING
 // the same two walks over the 4-wide collapse (hrt_walker_wide.hpp); production frames only (no work counters)
 template <int FEAT>
 HRT_D void wf_walkw_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange)
@@ -496,6 +499,7 @@ HRT_D void wf_walkw_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers&
             W.R.st4(RQ_H, slot, mkq(res.t, res.tObj, __int_as_float(res.slot), __int_as_float(res.prim)));
         });
 }
+#endif
 
 // next vertex or end of path from the raw winners (TraceNext :659-671, :241-243), with segmented compaction
 // The four waves of a workgroup own four consecutive ranges.  Their survivors are packed TOGETHER into the front of that

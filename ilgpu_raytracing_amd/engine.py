@@ -61,6 +61,10 @@ def lib():
         L.hrt_present.argtypes = [C.c_void_p, C.POINTER(T.PresentParams), C.c_void_p]
         L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
         L.hrt_reset_history.argtypes = [C.c_void_p]
+        L.hrt_frame_times.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.hrt_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.hrt_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+        L.hrt_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
         L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrt_device_count.restype = C.c_int
         L.hrt_version.restype = C.c_char_p
@@ -475,6 +479,27 @@ class RTRenderer:
         st = T.Stats()
         self._check(lib().hrt_synchronize(self._ctx, C.byref(st)))
         return st
+
+    def frame_times(self, launch=1, slot=0):
+        """Per-frame HIP-event times (ms) of the frames the last synchronize() / blocking frame collected."""
+        n = C.c_int(0)
+        self._check(lib().hrt_frame_times(self._ctx, slot, launch, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), np.float32)
+        self._check(lib().hrt_frame_times(self._ctx, slot, launch, out.ctypes.data, n.value, None))
+        return out[:n.value]
+
+    def register_host(self, arrays):
+        """Page-locks host arrays used as gather targets (hrt_host_register); arrays: dict or iterable of numpy arrays."""
+        for a in (arrays.values() if isinstance(arrays, dict) else arrays):
+            self._check(lib().hrt_host_register(self._ctx, a.ctypes.data, a.nbytes))
+
+    def unregister_host(self, arrays):
+        for a in (arrays.values() if isinstance(arrays, dict) else arrays):
+            self._check(lib().hrt_host_unregister(self._ctx, a.ctypes.data))
+
+    def set_workspace_limit(self, max_resident_paths):
+        """Caps the streamed pipeline's path workspace (0 = default): larger frames run in sample batches, same results."""
+        self._check(lib().hrt_set_workspace_limit(self._ctx, int(max_resident_paths)))
 
     def present(self, out_width, out_height, taau=True, out=None, feedback=0.0, sharpness=0.0, clamp_k=0.0):
         """Presentation step of RenderDirectToPbo (RTRenderer.cs:208-231): TAAU resolve, or blit / bilinear upsample.

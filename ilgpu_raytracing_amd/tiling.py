@@ -150,16 +150,25 @@ def all_gather_strips(arrays, height, world_size, rank, group=None):
             unpack_rows(arrays, rows[r], pad, recv[r])
 
 
-def render_reuse_frame(renderer, params, world_size, rank, group=None, flags=0, outputs=None):
+def render_reuse_frame(renderer, params, world_size, rank, group=None, flags=0, outputs=None, tensors_of=None, sync=None):
     """One frame with ReSTIR reuse ON, tiled over the ranks of `group` (this rank: strips rank mod world_size).
-    Returns (Stats of launch 1, Stats of launch 2).  Results are identical to a full-image render on one device."""
-    import torch
+    Returns (Stats of launch 1, Stats of launch 2).  Results are identical to a full-image render on one device.
+
+    `renderer` needs render_params(params, outputs, flags=, strips=) with the flag semantics of hrt_render_frame.
+    tensors_of(which, frame) -> the [H, X] arrays of one exchange phase ("gbuffer": GBUFFER_EXCHANGE, "reservoir":
+    RESERVOIR_FIELDS of resCur); default: torch tensors aliasing the library's device arrays (hrt_device_buffers).
+    sync(): waits for the exchange's device work; default torch.cuda.synchronize.  Both hooks exist so that the protocol
+    itself can be driven on CPU ranks (tests/test_tiling_dist.py, gloo, the oracle as tile renderer)."""
+    if tensors_of is None:
+        import torch
+        sync = sync or torch.cuda.synchronize
+        tensors_of = lambda which, frame: device_tensors(renderer.device_views(), which, frame)      # noqa: E731
+    sync = sync or (lambda: None)
     strips = (world_size, rank)
     st1 = renderer.render_params(params, None, flags=flags | T.FLAG_PRIMARY_ONLY, strips=strips)      # blocks until launch 1 is done
-    v = renderer.device_views()
-    all_gather_strips(device_tensors(v, "gbuffer"), params.height, world_size, rank, group)
-    torch.cuda.synchronize()
+    all_gather_strips(tensors_of("gbuffer", params.frame), params.height, world_size, rank, group)
+    sync()
     st2 = renderer.render_params(params, outputs, flags=flags | T.FLAG_SKIP_PRIMARY | T.FLAG_EXCHANGED, strips=strips)
-    all_gather_strips(device_tensors(v, "reservoir", params.frame), params.height, world_size, rank, group)
-    torch.cuda.synchronize()
+    all_gather_strips(tensors_of("reservoir", params.frame), params.height, world_size, rank, group)
+    sync()
     return st1, st2

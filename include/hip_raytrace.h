@@ -43,10 +43,14 @@
  *     pixel's value (RTUtils.cs:108-113, RTRay.cs:488).
  *   - hrt_render_frame blocks until the frame is complete; one call at a time per ctx.
  *
- * Multi-GPU: a ctx created on n devices splits the image into n contiguous row blocks
- * (scene replicated, no collective, per-tile hipMemcpyAsync gather into the caller's
- * host framebuffer).  One-process-per-GPU hosts instead create one ctx per process and
- * restrict it to a row range / strip set with hrt_render_opts.  With ReSTIR reuse enabled a multi-device ctx
+ * Multi-GPU: a ctx created on n devices cuts the image into 8-row strips and deals them
+ * round-robin to its devices (device slot i renders strips s with s % n == i: sky rows are
+ * cheap, geometry rows expensive, interleaving balances the tiles without knowing the image).
+ * The scene is replicated, there is no collective; every device's strips are gathered into the
+ * caller's host framebuffer by strided hipMemcpy2DAsync copies issued from one host thread per
+ * device.  Page-lock the framebuffer once with hrt_host_register and those copies are
+ * asynchronous DMA.  One-process-per-GPU hosts instead create one ctx per process and restrict
+ * it to a row range / strip set with hrt_render_opts.  With ReSTIR reuse enabled a multi-device ctx
  * exchanges G-buffer and reservoir tiles between its devices (device-to-device copies); partial tiles of a
  * one-process-per-GPU host are refused while reuse is on.
  *
@@ -253,8 +257,26 @@ int  hrt_render_frame(hrt_ctx* ctx, const hrt_frame_params* params,
 int  hrt_synchronize(hrt_ctx* ctx, hrt_stats* stats);
 
 /* out_color_host: out_width*out_height packed 0xFFRRGGBB, may be NULL (result stays in hrt_device_views.present_color).
- * Single-device contexts only; the last frame must have been a full-image render. */
+ * The last frame must have been a full-image render.  The resolve runs on device slot 0; a multi-device ctx first
+ * brings the colour / objectId strips of its other devices there (device-to-device copies). */
 int  hrt_present(hrt_ctx* ctx, const hrt_present_params* params, int32_t* out_color_host);
+
+/* Per-frame HIP-event times (ms) of the frames the last hrt_synchronize (or blocking hrt_render_frame) collected on device
+ * slot `dev`: launch 0 = primary visibility, 1 = the path-trace stage.  *n (may be NULL) receives their number; at most
+ * cap values are written to ms (may be NULL). */
+int  hrt_frame_times(hrt_ctx* ctx, int dev, int launch, float* ms, int cap, int* n);
+
+/* Page-locks (hipHostRegister, portable) a host range the caller will pass as hrt_outputs destination, e.g. the C# host's
+ * pinned framebuffer arrays (GCHandle.Alloc(..., Pinned)): gathers into it are asynchronous DMA instead of staged copies.
+ * The range must stay mapped until hrt_host_unregister / hrt_destroy.  Replaces nothing in the reference, whose frame never
+ * leaves the GPU (CudaGlInteropIndexBuffer.cs:37-194). */
+int  hrt_host_register(hrt_ctx* ctx, void* ptr, int64_t bytes);
+int  hrt_host_unregister(hrt_ctx* ctx, void* ptr);
+
+/* Caps the path-state workspace of the streamed pipeline at max_resident_paths paths (320 bytes each; 0 = the default of
+ * 2^25 paths = 10.7 GB): frames whose width*height*spp exceeds it run in several sample batches, with identical results.
+ * Counterpart of sizing MemoryBuffer1D allocations in the reference (Framebuffer.cs:60-97). */
+int  hrt_set_workspace_limit(hrt_ctx* ctx, int64_t max_resident_paths);
 
 int  hrt_device_buffers(hrt_ctx* ctx, int dev, hrt_device_views* out);
 int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */

@@ -29,6 +29,31 @@ CASES = {
 }
 
 
+# BASELINE.json configs[2..4] at their STATED size and sample count: one 8-row strip each (strip index in units of 8 rows,
+# chosen through the geometry), every output array of the strip's rows + the work counters of the strip.
+# name -> (config id, first row)
+FULL_STRIPS = {
+    "full_config3_1080p_16spp_rows304": (3, 304),
+    "full_config4_4k_64spp_rows1040": (4, 1040),
+    "full_config5_4k_256spp_rows800": (5, 800),
+}
+FULL_NAMES = ["color", "depth", "objectId", "radiance", "gb_hitMask", "gb_worldPos", "gb_normalWS", "gb_objId",
+              "res_L", "res_wi", "res_pdf", "res_w", "res_wSum", "res_m", "res_lightId"]
+
+
+def render_full_strip(orc, name):
+    cfg_id, y0 = FULL_STRIPS[name]
+    cfg = scenes.CONFIGS[cfg_id]
+    builder = {3: scenes.build_config3, 4: scenes.build_config4, 5: scenes.build_config5}[cfg_id]
+    w, h = cfg.width, cfg.height
+    arrs, st, _ = H.oracle_frame(orc, builder, cfg, w, h, cfg.spp, rows=(y0, y0 + 8))
+    out = {}
+    for k in FULL_NAMES:
+        a = arrs[k]
+        out[k] = np.ascontiguousarray(a.reshape(h, w, *a.shape[1:])[y0:y0 + 8])
+    return out, st
+
+
 def render_case(orc, name):
     builder, cfg, w, h, spp, reuse_frames = CASES[name]
     if reuse_frames == 0:
@@ -46,7 +71,20 @@ def render_case(orc, name):
 def main():
     from oracle import orc
     orc.build()
+    only = sys.argv[1:]
+    import time
+    for name in FULL_STRIPS:
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        out, st = render_full_strip(orc, name)
+        out["counters_json"] = np.array(json.dumps([st.k[0].as_dict(), st.k[1].as_dict()]))
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes, oracle %.1f s" % (time.time() - t0), flush=True)
     for name in CASES:
+        if only and name not in only:
+            continue
         arrs, st = render_case(orc, name)
         out = {k: v for k, v in arrs.items()}
         out["counters_json"] = np.array(json.dumps([st.k[0].as_dict(), st.k[1].as_dict()]))

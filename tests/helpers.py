@@ -5,10 +5,19 @@ from ilgpu_raytracing_amd import _types as T, scenes
 
 
 def bits_equal(a, b):
-    """Element-wise equality that treats NaN == NaN and +0 == -0 for floats, exact for ints."""
+    """Element-wise LITERAL equality: floats are compared as their 32-bit patterns (so +0 != -0); the one tolerance
+    is that any NaN equals any NaN (x86-64 and gfx950 propagate different NaN payloads).  Integers exact."""
     if a.dtype == np.float32:
-        return (a == b) | (np.isnan(a) & np.isnan(b))
+        ua, ub = np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)
+        return (ua == ub) | (np.isnan(a) & np.isnan(b))
     return a == b
+
+
+def zero_sign_only(a, b):
+    """Elements that are equal as floats but not as bit patterns (+0 vs -0): reported separately in failures."""
+    if a.dtype != np.float32:
+        return np.zeros(a.shape, dtype=bool)
+    return (a == b) & ~bits_equal(a, b)
 
 
 def assert_outputs_equal(ref, got, names=None, rows=None, width=None):
@@ -22,8 +31,8 @@ def assert_outputs_equal(ref, got, names=None, rows=None, width=None):
             b = b.reshape(-1, width, *b.shape[1:])[rows[0]:rows[1]]
         n = int(np.count_nonzero(~bits_equal(a, b)))
         if n:
-            bad[k] = n
-    assert not bad, "arrays differ from the oracle (element counts): %s" % bad
+            bad[k] = (n, int(np.count_nonzero(zero_sign_only(a, b))))
+    assert not bad, "arrays differ from the oracle {array: (elements, of which only in the sign of a zero)}: %s" % bad
 
 
 def host_funcs(kind, orc=None):

@@ -101,16 +101,20 @@ def test_frame_matches_oracle(orc, renderer, name, mode):
     assert gst.n_devices == 1
 
 
-def test_streamed_sample_batches(orc, renderer, monkeypatch):
+def test_streamed_sample_batches(orc, renderer):
     """spp larger than what fits the path workspace is processed in sample batches: Lframe is carried across
-    batches in sample order and resCur keeps the last writer.  HRT_WF_MAX_PATHS shrinks the workspace so that a
-    small frame needs 1-, 2- and 3-sample batches (7 spp -> 3 + 3 + 1 and 2 + 2 + 2 + 1)."""
+    batches in sample order and resCur keeps the last writer.  hrt_set_workspace_limit shrinks the workspace so that a
+    small frame needs 1-, 2- and 3-sample batches (7 spp -> 3 + 3 + 1 and 2 + 2 + 2 + 1); tests/test_full_size_gpu.py
+    runs the same path at the default limit with 4K frames of 64 / 256 spp."""
     builder, cfg, w, h, spp = scenes.build_textured_test_scene, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0)), 96, 64, 7
     ref, ost, _ = H.oracle_frame(orc, builder, cfg, w, h, spp)
     n_ord = ((w + 7) // 8) * ((h + 7) // 8) * 64
     for per_batch in (3, 2, 1):
-        monkeypatch.setenv("HRT_WF_MAX_PATHS", str(n_ord * per_batch + 5))
-        got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, flags=T.FLAG_COUNTERS | T.FLAG_STREAMED)
+        renderer.set_workspace_limit(n_ord * per_batch + 5)
+        try:
+            got, gst, _ = _gpu_frame(renderer, builder, cfg, w, h, spp, flags=T.FLAG_COUNTERS | T.FLAG_STREAMED)
+        finally:
+            renderer.set_workspace_limit(0)
         H.assert_outputs_equal(ref, got)
         assert gst.k[1].as_dict() == ost.k[1].as_dict()
 

@@ -101,8 +101,43 @@ dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 cfg = scenes.CONFIGS[2]; w, h, spp = 64, 44, 1            # 6 strips, the last one 4 rows: ragged tiles
 so = orc.OrcScene(); scenes.build_config2(so)
-arrs, o = T.alloc_outputs(w, h)                            # this rank's "device" arrays (whole image, only its strips valid)
-A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+
+
+class OracleTileRenderer:
+    # what tiling.render_reuse_frame needs from a renderer, backed by the CPU oracle: whole-image host arrays of which only
+    # this rank's strips are rendered, reservoir sets A / B picked by frame parity (Framebuffer.cs:132-145), and the
+    # PRIMARY_ONLY / SKIP_PRIMARY flags of hrt_render_frame
+    def __init__(self):
+        self.arrs, self.o = T.alloc_outputs(w, h)
+        self.A, self.B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+
+    def pair(self, frame):
+        return (self.B, self.A) if frame %% 2 == 0 else (self.A, self.B)
+
+    def render_params(self, p, outputs=None, flags=0, strips=None):
+        prev, cur = self.pair(p.frame)
+        for k, a in cur.items():
+            self.arrs[k] = a; setattr(self.o, k, a.ctypes.data)
+        po = T.Outputs()
+        for k, a in prev.items():
+            setattr(po, k, a.ctypes.data)
+        assert bool(flags & T.FLAG_PRIMARY_ONLY) != bool(flags & T.FLAG_SKIP_PRIMARY)
+        if flags & T.FLAG_SKIP_PRIMARY:
+            assert flags & T.FLAG_EXCHANGED
+        mode = 2 if (flags & T.FLAG_PRIMARY_ONLY) else False
+        n, i = strips
+        for s in range(i, (h + 7) // 8, n):
+            orc.render_frame(so.desc(), p, self.o, po, row_begin=8 * s, row_end=min(h, 8 * s + 8), run_primary=mode, nthreads=1)
+        return T.Stats()
+
+    def tensors_of(self, which, frame):
+        if which == "gbuffer":
+            return [self.arrs[n].reshape(h, -1) for n, _, _ in tiling.GBUFFER_EXCHANGE]
+        cur = self.pair(frame)[1]
+        return [cur["res_" + n].reshape(h, -1) for n, _, _ in tiling.RESERVOIR_FIELDS]
+
+
+tile = OracleTileRenderer()
 full, fo = T.alloc_outputs(w, h)                           # rank 0 also renders the full image for comparison
 FA, FB = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
 prev_cam = None
@@ -110,20 +145,8 @@ for f in range(3):
     origin = (0.2 * f, 1.5, 5.5 - 0.15 * f)                # moving camera: temporal reprojection crosses tiles
     c2 = scenes.Config("mv", w, h, spp, origin, cfg.cam_lookat, extra=cfg.extra)
     p = scenes.frame_params(c2, *H.host_funcs("orc", orc), frame=f, reuse=True, prev_cam=prev_cam)
-    prev, cur = (B, A) if f %% 2 == 0 else (A, B)
-    for k, a in cur.items():
-        arrs[k] = a; setattr(o, k, a.ctypes.data)
-    po = T.Outputs()
-    for k, a in prev.items():
-        setattr(po, k, a.ctypes.data)
-    strips = range(rank, (h + 7) // 8, world)
-    for s in strips:                                       # launch 1 on this rank's strips
-        orc.render_frame(so.desc(), p, o, po, row_begin=8 * s, row_end=min(h, 8 * s + 8), run_primary=2, nthreads=1)
-    gb = [arrs[n].reshape(h, -1) for n, _, _ in tiling.GBUFFER_EXCHANGE]
-    tiling.all_gather_strips(gb, h, world, rank)
-    for s in strips:                                       # launch 2 on this rank's strips, G-buffer and resPrev complete
-        orc.render_frame(so.desc(), p, o, po, row_begin=8 * s, row_end=min(h, 8 * s + 8), run_primary=False, nthreads=1)
-    tiling.all_gather_strips([cur["res_" + n].reshape(h, -1) for n, _, _ in tiling.RESERVOIR_FIELDS], h, world, rank)
+    tiling.render_reuse_frame(tile, p, world, rank, tensors_of=tile.tensors_of)      # the product's protocol, unmodified
+    arrs = tile.arrs
     if rank == 0:
         fprev, fcur = (FB, FA) if f %% 2 == 0 else (FA, FB)
         for k, a in fcur.items():
@@ -146,8 +169,8 @@ dist.destroy_process_group()
 
 
 def test_two_rank_reuse_tile_exchange_gloo(tmp_path):
-    """The exchange protocol of tiling.render_reuse_frame (launch 1 -> all-gather G-buffer -> launch 2 -> all-gather
-    resCur) driven with the oracle as the tile renderer on two gloo ranks: 3 reuse frames with a moving camera end up
+    """tiling.render_reuse_frame ITSELF (launch 1 -> all-gather G-buffer -> launch 2 -> all-gather resCur) on two gloo
+    ranks, with the oracle behind the renderer interface it calls: 3 reuse frames with a moving camera end up
     byte-identical to full-image frames."""
     script = tmp_path / "reuse_worker.py"
     script.write_text(REUSE_WORKER % {"root": ROOT})
