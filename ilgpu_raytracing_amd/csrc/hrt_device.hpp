@@ -24,6 +24,16 @@
 
 #define HRT_D __device__ __forceinline__
 
+// Tuning aid (variant build -DHRT_PT_STATS, tools/pt_stats.py): how often each section of the fused kernel runs and with how
+// many live lanes.  g_pt_stats[2 i] = executions of section i (per wave), [2 i + 1] = live lanes summed.
+#ifdef HRT_PT_STATS
+__device__ unsigned long long g_pt_stats[64];
+#define PSTAT(i) { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
+                   if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { atomicAdd(&g_pt_stats[2 * (i)], 1ull); atomicAdd(&g_pt_stats[2 * (i) + 1], (unsigned long long)__popcll(m_)); } }
+#else
+#define PSTAT(i)
+#endif
+
 namespace hrt {
 
 // ------------------------------------------------------------------ small vector type
@@ -39,9 +49,40 @@ HRT_D F3 operator*(F3 a, F3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
 HRT_D F3 operator-(F3 a) { return mk3(-a.x, -a.y, -a.z); }
 HRT_D float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HRT_D F3 cross(F3 a, F3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+// IEEE square root for arguments that are +0, +inf or normal numbers >= 2^-96: the same v_sqrt_f32 + two one-ulp
+// corrections hipcc emits for sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt), minus the rescaling of tiny arguments and
+// the class test for infinities -- 7 of its 17 instructions.  tests/test_math_gpu.py compares it with hrt_sqrt over every
+// argument the sampler below can produce and over [1e-20, 1e20].
+HRT_D float sqrt_normal_range(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sDn = __int_as_float(__float_as_int(s) - 1), sUp = __int_as_float(__float_as_int(s) + 1);
+    const float rDn = __builtin_fmaf(-sDn, s, x), rUp = __builtin_fmaf(-sUp, s, x);
+    float r = (rDn <= 0.f) ? sDn : s;
+    r = (rUp > 0.f) ? sUp : r;
+    return (x == 0.f) ? x : r;
+}
+// hrt_rsqrt(x) = 1 / sqrt(x), both IEEE, for x = max(1e-20, .): x in [2^-67, +inf], never NaN -- the argument of every
+// Normalize (Float3.cs:91-95).  sqrt: the trimmed form above.  1 / s with s in [2^-34, 2^64]: the division sequence hipcc
+// emits for 1.0f / s minus what these operands cannot need: v_div_scale (no operand is scaled when the denominator and the
+// quotient are normal numbers far from the exponent limits), the scaling half of v_div_fmas and the special-case v_div_fixup,
+// of which only s = +inf (|v|^2 overflowed) remains and is handled by the select.  16 instructions instead of 28;
+// tests/test_math_gpu.py compares it with hrt_rsqrt on the device for EVERY float in the domain.
+HRT_D float rsqrt_clamped(float x)
+{
+    const float s = sqrt_normal_range(x);
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    const float e0 = __builtin_fmaf(-s, r0, 1.f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float e1 = __builtin_fmaf(-s, r1, 1.f);           // numerator 1: n * r1 == r1
+    const float q1 = __builtin_fmaf(e1, r1, r1);
+    const float e2 = __builtin_fmaf(-s, q1, 1.f);
+    const float q = __builtin_fmaf(e2, r1, q1);
+    return (s == __builtin_inff()) ? 0.f : q;
+}
 HRT_D F3 normalize(F3 v)   // Float3.cs:91-95
 {
-    float inv = hrt_rsqrt(hrt_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z));
+    float inv = rsqrt_clamped(hrt_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z));
     return mk3(v.x * inv, v.y * inv, v.z * inv);
 }
 HRT_D F3 inv_dir(F3 d)     // RTRay.cs:548-549
@@ -195,23 +236,26 @@ HRT_D bool hit_aabb(const Ray& r, const hrt_bvh_node* n, float tMin, float tMax)
 }
 
 // SceneDeviceViews.cs:517-533 without the normal (:534-535 is a pure function of t: deferred)
-HRT_D bool hit_sphere_t(const Ray& r, F3 c, float radius, float& t)
+// a = dot(r.d, r.d) is a property of the ray: callers that test several spheres with one ray compute it once
+HRT_D bool hit_sphere_ta(const Ray& r, float a, F3 c, float radius, float& t)
 {
     F3 oc = r.o - c;
-    float a = dot(r.d, r.d);
     float b = 2.f * dot(oc, r.d);
     float cc = dot(oc, oc) - radius * radius;
     float disc = b * b - 4.f * a * cc;
     if (disc < 0.f) return false;
+    PSTAT(9);
     float sq = hrt_sqrt(disc);
     float tt = (-b - sq) / (2.f * a);
     if (tt < 0.001f) {
+        PSTAT(10);
         tt = (-b + sq) / (2.f * a);
         if (tt < 0.001f) return false;
     }
     t = tt;
     return true;
 }
+HRT_D bool hit_sphere_t(const Ray& r, F3 c, float radius, float& t) { return hit_sphere_ta(r, dot(r.d, r.d), c, radius, t); }
 HRT_D F3 sphere_normal(const Ray& r, F3 c, float t) { return normalize((r.o + r.d * t) - c); }   // :534-535
 
 // SceneDeviceViews.cs:540-555 without the normal (:556 deferred)
@@ -651,19 +695,6 @@ HRT_D Frame make_frame(F3 n)
     f.b = cross(n, f.t);
     return f;
 }
-// IEEE square root for arguments that are +0 or normal numbers >= 2^-96 (finite): the same v_sqrt_f32 + two one-ulp
-// corrections hipcc emits for sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt), minus the rescaling of tiny arguments and
-// the class test for infinities -- 7 of its 17 instructions.  tests/test_math_gpu.py compares it with hrt_sqrt over every
-// argument the sampler below can produce and over [1e-20, 1e20].
-HRT_D float sqrt_normal_range(float x)
-{
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sDn = __int_as_float(__float_as_int(s) - 1), sUp = __int_as_float(__float_as_int(s) + 1);
-    const float rDn = __builtin_fmaf(-sDn, s, x), rUp = __builtin_fmaf(-sUp, s, x);
-    float r = (rDn <= 0.f) ? sDn : s;
-    r = (rUp > 0.f) ? sUp : r;
-    return (x == 0.f) ? x : r;
-}
 HRT_D F3 sample_hemisphere_cosine(const Frame& f, Rng& rng)
 {
     float r1 = rng.next_f(), r2 = rng.next_f();          // k / 2^24: r2 is 0 or >= 2^-24, 1 - r2 is >= 2^-24
@@ -877,8 +908,11 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             ior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
             I = normalize(pos - cv3(k.cam.origin));
         };
-        Res lastRes; bool haveRes = false;
-        lastRes.L = lastRes.wi = mk3(0.f, 0.f, 0.f); lastRes.pdf = lastRes.w = lastRes.wSum = 0.f; lastRes.m = lastRes.lightId = 0;
+        // resCur.Write (:42-47): every sample's first diffuse vertex writes the same slot and only the last write survives.
+        // The latest one waits in the lane's own LDS column (11 dwords, [field][thread]: conflict-free) instead of 11 registers
+        // held across the whole bounce loop, and is stored once after the sample loop ((spp-1) x 44 B/pixel of HBM writes saved).
+        __shared__ float s_res[11][256];
+        bool haveRes = false;
 
         // Lanes do not wait for each other at sample boundaries: every lane runs its own (sample, depth)
         // cursor through one flat bounce loop, so a lane whose path ended starts its next sample while its
@@ -892,18 +926,21 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
 
         while (s < spp)
         {
+            PSTAT(0);
             bool ended = false;
             {
                 Ray ray;
                 bool terminated = false;
                 if (shade == HRT_SHADING_MIRROR)
                 {   // :235-244
+                    PSTAT(1);
                     F3 dirR = I - nrm * (2.f * dot(I, nrm));
                     ray = ray_with_normal_offset(pos, nrm, dirR);
                     T = T * alb;
                 }
                 else if (shade == HRT_SHADING_GLASS)
                 {   // :246-275
+                    PSTAT(2);
                     F3 Nuse = nrm;
                     bool outside = dot(I, nrm) < 0.f;
                     if (!outside) Nuse = Nuse * -1.f;
@@ -937,6 +974,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 }
                 else
                 {   // :277-317
+                    PSTAT(3);
                     Frame fr = make_frame(nrm);
                     Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !wroteReservoir, pos, fr, alb, rng, C);
                     // (5) final shading with one visibility ray :518-539
@@ -949,6 +987,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                         // Visible(): nl <= 0 -> false (:620-621); nlSel > 0 implies it
                         if (nlSel > 0.f)
                         {
+                            PSTAT(4);
                             Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
                             if (!tr.template occluded<COUNT>(sray, 1e29f, C))
                             {
@@ -962,10 +1001,11 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                     }
                     Li = Li + T * contrib;       // :286/:291, also when contrib == 0
                     if (!wroteReservoir)
-                    {   // resCur.Write :42-47.  Every sample's first diffuse vertex writes the same slot and only
-                        // the last write survives: keep it in registers, store once after the sample loop
-                        // (saves (spp-1) x 44 B/pixel of HBM writes).
-                        lastRes = r; haveRes = true;
+                    {
+                        const int t = threadIdx.x;
+                        s_res[0][t] = r.L.x; s_res[1][t] = r.L.y; s_res[2][t] = r.L.z; s_res[3][t] = r.wi.x; s_res[4][t] = r.wi.y; s_res[5][t] = r.wi.z;
+                        s_res[6][t] = r.pdf; s_res[7][t] = r.w; s_res[8][t] = r.wSum; s_res[9][t] = __int_as_float(r.m); s_res[10][t] = __int_as_float(r.lightId);
+                        haveRes = true;
                         wroteReservoir = true;
                     }
                     F3 wi = sample_hemisphere_cosine(fr, rng);
@@ -982,6 +1022,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 if (terminated) ended = true;
                 else
                 {   // TraceNext :659-671 -- the one closest-hit site of the bounce loop
+                    PSTAT(5);
                     Hit h;
                     if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); ended = true; }
                     else
@@ -997,6 +1038,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             }
             if (ended)
             {
+                PSTAT(6);
                 add_sample(s, safe_color(Li));                     // :320
                 s++;
                 if (s < spp)
@@ -1016,15 +1058,17 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             st[11 * P] = haveRes ? 1.f : 0.f;
             if (haveRes)
             {
-                st[0] = lastRes.L.x; st[P] = lastRes.L.y; st[2 * P] = lastRes.L.z; st[3 * P] = lastRes.wi.x; st[4 * P] = lastRes.wi.y; st[5 * P] = lastRes.wi.z;
-                st[6 * P] = lastRes.pdf; st[7 * P] = lastRes.w; st[8 * P] = lastRes.wSum; st[9 * P] = __int_as_float(lastRes.m); st[10 * P] = __int_as_float(lastRes.lightId);
+                const int t = threadIdx.x;
+#pragma unroll
+                for (int f = 0; f < 11; f++) st[f * P] = s_res[f][t];
             }
         }
         else if (haveRes)
         {
-            resCur.L[index] = to3(lastRes.L); resCur.wi[index] = to3(lastRes.wi); resCur.pdf[index] = lastRes.pdf;
-            resCur.w[index] = lastRes.w; resCur.wSum[index] = lastRes.wSum; resCur.lightId[index] = lastRes.lightId;
-            resCur.m[index] = lastRes.m;
+            const int t = threadIdx.x;
+            resCur.L[index] = to3(mk3(s_res[0][t], s_res[1][t], s_res[2][t])); resCur.wi[index] = to3(mk3(s_res[3][t], s_res[4][t], s_res[5][t]));
+            resCur.pdf[index] = s_res[6][t]; resCur.w[index] = s_res[7][t]; resCur.wSum[index] = s_res[8][t];
+            resCur.lightId[index] = __float_as_int(s_res[10][t]); resCur.m[index] = __float_as_int(s_res[9][t]);
         }
     }
     if (SPLIT) return;

@@ -24,6 +24,7 @@
 // lookups are pure functions of the winner and are evaluated once, after the walk.
 #pragma once
 #include "hrt_device.hpp"
+#include <hip/hip_fp16.h>
 
 namespace hrt {
 
@@ -54,6 +55,10 @@ struct DPacked {
     int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
     const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
+    // slot streams of the persistent walker (hrt_bvh.hpp "node streams"): the TLAS in use (tlasX when built, else tlas) and all BLASes.
+    // info[0] = slots in use.  General leaf slots carry their BLAS' slot range in FInst a.x / a.y.
+    const float4* sTop; const int* sTopInfo;
+    const float4* sBlas; const int* sBlasInfo;
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514
@@ -71,6 +76,18 @@ HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)  
     tmin = hrt_fmax(tmin, hrt_fmin(t1, t2));
     tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
     return tmax >= hrt_fmax(tmin, tMin) && tmin <= tMax;
+}
+// Box test of an inner slot (six half-precision bounds rounded outward, hrt_bvh.hpp): the same slab test on the decoded box.
+// Conservative by monotonicity of the test in the box, which needs finite slab arithmetic: callers route rays with a
+// non-finite origin or 1/d to the exact records.
+HRT_D float half_lo(float packed) { return __half2float(__ushort_as_half((unsigned short)(__float_as_uint(packed) & 0xFFFFu))); }
+HRT_D float half_hi(float packed) { return __half2float(__ushort_as_half((unsigned short)(__float_as_uint(packed) >> 16))); }
+HRT_D bool hit_box_h(const Ray& r, float4 s, float tMin, float tMax)
+{
+    float4 lo, hi;
+    lo.x = half_lo(s.x); lo.y = half_hi(s.x); lo.z = half_lo(s.y); hi.x = half_hi(s.y); hi.y = half_lo(s.z); hi.z = half_hi(s.z);
+    lo.w = hi.w = 0.f;
+    return hit_box(r, lo, hi, tMin, tMax);
 }
 // The world ray is dead weight while a general instance's BLAS is walked with the object-space
 // ray, but it must survive for the rest of the TLAS walk.  hipcc can only spill to scratch
@@ -107,6 +124,11 @@ HRT_D F3 ident_vector(F3 v)
     return mk3((1.f * v.x + 0.f * v.y) + 0.f * v.z, (0.f * v.x + 1.f * v.y) + 0.f * v.z, (0.f * v.x + 0.f * v.y) + 1.f * v.z);
 }
 HRT_D int wbits(float4 v) { return __float_as_int(v.w); }
+HRT_D bool finite_ray(const Ray& r)
+{
+    return hrt_isfinite(r.inv.x) && hrt_isfinite(r.inv.y) && hrt_isfinite(r.inv.z) &&
+           hrt_isfinite(r.o.x) && hrt_isfinite(r.o.y) && hrt_isfinite(r.o.z);
+}
 
 // FEAT bit 0: the scene has leaf slots that are not fast spheres (general walkers compiled in)
 // FEAT bit 1: some triangle needs the in-walk alpha / texture path (FT_TEXTURED)
@@ -548,31 +570,30 @@ struct TracerFlat {
     const NodeQ* leaves;         // TLAS leaf records in walk order
     int nLeaves;
 
-    HRT_D static bool finite_ray(const Ray& r)
-    {
-        return hrt_isfinite(r.inv.x) && hrt_isfinite(r.inv.y) && hrt_isfinite(r.inv.z) &&
-               hrt_isfinite(r.o.x) && hrt_isfinite(r.o.y) && hrt_isfinite(r.o.z);
-    }
-
     template <bool COUNT>
     HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
     {
         if (COUNT || !finite_ray(wray)) return tree.template closest<COUNT>(wray, best, C);
         float bestT = 1e30f; int bestSlot = -1, bestPrim = -1;
+        const float a = dot(wray.d, wray.d);
         for (int l = 0; l < nLeaves; l++)
         {
             const NodeQ n = leaves[l];
+            PSTAT(14);
             if (!hit_box(wray, n.lo, n.hi, 0.001f, bestT)) continue;
             const int first = wbits(n.lo), cnt = (int)((unsigned)wbits(n.hi) >> 28);
             for (int i = first; i < first + cnt; i++)
             {
                 const FInst f = tree.P.finst[i];
+                PSTAT(7);
                 if (!hit_box(wray, f.a, f.b, 0.001f, 1e30f)) continue;
+                PSTAT(8);
                 float t;
-                if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < 1e30f && t < 1e29f && t < bestT)
+                if (hit_sphere_ta(wray, a, xyz(f.c), f.c.w, t) && t > 0.001f && t < 1e30f && t < 1e29f && t < bestT)
                 { bestT = t; bestSlot = i; bestPrim = wbits(f.b); }
             }
         }
+        PSTAT(13);
         return tree.finish_hit(wray, bestT, bestT, bestSlot, bestPrim, best);
     }
 
@@ -581,17 +602,21 @@ struct TracerFlat {
     {
         if (COUNT || !finite_ray(wray)) return tree.template occluded<COUNT>(wray, tMaxWorld, C);
         bool hit = false;
+        const float a = dot(wray.d, wray.d);
         for (int l = 0; l < nLeaves; l++)
         {
             const NodeQ n = leaves[l];
+            PSTAT(15);
             if (hit || !hit_box(wray, n.lo, n.hi, 0.001f, tMaxWorld)) continue;
             const int first = wbits(n.lo), cnt = (int)((unsigned)wbits(n.hi) >> 28);
             for (int i = first; i < first + cnt; i++)
             {
                 const FInst f = tree.P.finst[i];
+                PSTAT(11);
                 if (hit || !hit_box(wray, f.a, f.b, 0.001f, tMaxWorld)) continue;
+                PSTAT(12);
                 float t;
-                if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < tMaxWorld) hit = true;
+                if (hit_sphere_ta(wray, a, xyz(f.c), f.c.w, t) && t > 0.001f && t < tMaxWorld) hit = true;
             }
             if (__builtin_amdgcn_ballot_w64(!hit) == 0) break;      // every live lane is occluded
         }

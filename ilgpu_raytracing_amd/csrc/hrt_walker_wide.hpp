@@ -33,10 +33,6 @@ constexpr int kWStackOvf = 52;      // further levels per lane in global memory
 constexpr int kWideBurst = HRT_WIDE_BURST;
 constexpr int kWideMaxDepth = (kWStackLds + kWStackOvf - 2) / 3;
 
-HRT_D bool finite_ray(const Ray& r)
-{
-    return hrt_isfinite(r.inv.x) && hrt_isfinite(r.inv.y) && hrt_isfinite(r.inv.z) && hrt_isfinite(r.o.x) && hrt_isfinite(r.o.y) && hrt_isfinite(r.o.z);
-}
 
 HRT_D bool hit_box6(const Ray& r, float lx, float ly, float lz, float hx, float hy, float hz, float tMin, float tMax)   // hit_box on split coordinates
 {

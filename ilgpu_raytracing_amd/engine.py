@@ -66,6 +66,7 @@ def lib():
         L.hrt_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
         L.hrt_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
         L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.hrt_math_exhaustive.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.hrt_device_count.restype = C.c_int
         L.hrt_version.restype = C.c_char_p
         L.hrth_scene_new.restype = C.c_void_p
@@ -525,6 +526,12 @@ class RTRenderer:
         v = T.DeviceViews()
         self._check(lib().hrt_device_buffers(self._ctx, slot, C.byref(v)))
         return v
+
+    def math_exhaustive(self, which):
+        """(mismatches, bits of the first one) of a trimmed device function against its IEEE definition over its whole domain."""
+        n, first = C.c_uint64(0), C.c_uint32(0)
+        self._check(lib().hrt_math_exhaustive(self._ctx, which, C.byref(n), C.byref(first)))
+        return n.value, first.value
 
     def math_probe(self, fn, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -286,6 +286,11 @@ int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */
  * arithmetic contract against the oracle.  Not needed by a production host. */
 int  hrt_math_probe(hrt_ctx* ctx, int fn, int n, const float* x, const float* y, float* out);
 
+/* test hook: compares a trimmed device-side function with its IEEE definition for EVERY float of its stated domain, on the
+ * device (which: 0 = 1/sqrt(x) of Normalize for x in [1e-20, +inf], 1 = the square root of the hemisphere sampler for +0 and
+ * [2^-96, +inf]).  *mismatches = number of differing results (0 expected), *first_bad (may be NULL) = bits of the smallest one. */
+int  hrt_math_exhaustive(hrt_ctx* ctx, int which, uint64_t* mismatches, uint32_t* first_bad);
+
 int  hrt_device_count(void);                    /* visible HIP devices, <0 on error */
 const char* hrt_version(void);
 

@@ -72,3 +72,18 @@ def test_sqrt_normal_range_equals_ieee_sqrt(orc, renderer):
         a = orc.math_eval("sqrt", x)
         b = renderer.math_probe(22, x)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_trimmed_functions_equal_ieee_on_every_float_of_their_domain(orc, renderer):
+    """rsqrt_clamped (the 1 / sqrt of every Normalize: x in [1e-20, +inf]) and sqrt_normal_range (+0, [2^-96, +inf]) against the
+    IEEE definitions, exhaustively on the device: about 1.2 and 1.7 thousand million floats.  Plus a sample against the oracle's
+    bits on x86-64, so that 'IEEE on the device' is itself pinned."""
+    for which in (0, 1):
+        bad, first = renderer.math_exhaustive(which)
+        assert bad == 0, "function %d differs from IEEE for %d floats, first bits 0x%08X" % (which, bad, first)
+    rng = np.random.default_rng(16)
+    x = np.concatenate([(10.0 ** rng.uniform(-20, 38, 2000000)).astype(np.float32), np.array([1e-20, 1.0, 3.4e38, np.inf], np.float32)])
+    x = np.maximum(x, np.float32(1e-20))
+    a = orc.math_eval("rsqrt", x)
+    b = renderer.math_probe(23, x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
