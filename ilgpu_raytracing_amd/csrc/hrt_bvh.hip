@@ -7,7 +7,6 @@
 // the sort of the Morton keys (hipCUB radix sort, stable, so equal keys keep item order and the trees are deterministic).
 #include "hrt_bvh.hpp"
 #include <hipcub/hipcub.hpp>
-#include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
@@ -818,85 +817,6 @@ hipError_t tlas_rebound_instances(const TlasDevice& T, const int32_t* idsDev, in
 {
     if (n <= 0) return hipSuccess;
     k_set_transforms<<<blocks_for(n), kBlock, 0, s>>>(T, idsDev, nullptr, n);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------ slot streams (hrt_bvh.hpp)
-namespace {
-// half precision, rounded toward -inf (down = true) or +inf: the nearest half, stepped once if it lies on the wrong side
-HRT_D unsigned half_outward(float x, bool down)
-{
-    if (x != x) return down ? 0xFC00u : 0x7C00u;                  // NaN bound: the widest box
-    const __half hn = __float2half_rn(x);
-    unsigned h = (unsigned)__half_as_ushort(hn);
-    const float back = __half2float(hn);
-    if (down ? (back > x) : (back < x))
-    {   // one step toward the wanted side: on the half's bit pattern, +1 moves away from zero, -1 toward it
-        const bool neg = (h & 0x8000u) != 0;
-        if ((h & 0x7FFFu) == 0) h = down ? 0x8001u : 0x0001u;      // from a zero to the smallest subnormal of the wanted sign
-        else h = (down == neg) ? h + 1 : h - 1;
-    }
-    return h & 0xFFFFu;
-}
-__global__ void __launch_bounds__(kBlock) k_slot_sizes(const NodeQ* nodes, int n, SlotStream S)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i > n) return;
-    S.sizes[i] = i == n ? 0 : (node_cnt(nodes, i) > 0 ? 2 : 1);
-    if (i == 0) S.info[1] = 0;
-}
-__global__ void __launch_bounds__(kBlock) k_slot_write(const NodeQ* nodes, int n, SlotStream S)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const NodeQ q = nodes[i];
-    const int cnt = node_cnt(nodes, i), sk = node_skip(nodes, i), link = node_link(nodes, i);
-    const int o = S.off[i];
-    const int skS = (sk == kEnd || sk >= n) ? kEnd : S.off[sk];
-    if (cnt > 0)
-    {
-        S.slots[o] = make_float4(q.lo.x, q.lo.y, q.lo.z, i2f(skS | (int)((unsigned)cnt << 28)));
-        S.slots[o + 1] = make_float4(q.hi.x, q.hi.y, q.hi.z, i2f(link));
-    }
-    else
-    {
-        // the walker enters the NEXT slot after a hit: true in walk order; anything else (or an inner node without children,
-        // whose hit ends the walk) makes the stream unusable and the walker keeps the exact records
-        if ((link & kEnd) != i + 1) S.info[1] = 1;
-        const unsigned lx = half_outward(q.lo.x, true), ly = half_outward(q.lo.y, true), lz = half_outward(q.lo.z, true);
-        const unsigned hx = half_outward(q.hi.x, false), hy = half_outward(q.hi.y, false), hz = half_outward(q.hi.z, false);
-        S.slots[o] = make_float4(i2f((int)(lx | (ly << 16))), i2f((int)(lz | (hx << 16))), i2f((int)(hy | (hz << 16))), i2f(skS));
-    }
-    if (i == n - 1) S.info[0] = o + (cnt > 0 ? 2 : 1);
-}
-__global__ void __launch_bounds__(kBlock) k_slot_patch_finst(FInst* finst, int nTI, const int* off, int nB)
-{
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nTI) return;
-    FInst f = finst[i];
-    if (f2i(f.a.w) & FI_FAST_SPHERE) return;
-    const int b0 = f2i(f.c.x), b1 = f2i(f.c.y);
-    f.a.x = i2f(b0 >= 0 && b0 <= nB ? off[b0] : 0);
-    f.a.y = i2f(b1 >= 0 && b1 <= nB ? off[b1] : 0);
-    finst[i] = f;
-}
-} // namespace
-
-hipError_t slots_build(const NodeQ* nodes, int n, const SlotStream& S, void* scanTmp, size_t scanTmpBytes, hipStream_t s)
-{
-    if (n <= 0 || n > S.cap) return hipErrorInvalidValue;
-    k_slot_sizes<<<blocks_for(n + 1), kBlock, 0, s>>>(nodes, n, S);
-    size_t bytes = scanTmpBytes;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(scanTmp, bytes, (const int*)S.sizes, S.off, n + 1, s);
-    if (e != hipSuccess) return e;
-    k_slot_write<<<blocks_for(n), kBlock, 0, s>>>(nodes, n, S);
-    return hipGetLastError();
-}
-
-hipError_t slots_patch_finst(FInst* finst, int nTI, const int* blasOff, int nB, hipStream_t s)
-{
-    if (nTI <= 0) return hipSuccess;
-    k_slot_patch_finst<<<blocks_for(nTI), kBlock, 0, s>>>(finst, nTI, blasOff, nB);
     return hipGetLastError();
 }
 

@@ -179,26 +179,25 @@ hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigne
 }
 
 // persistent-wave walk kernels (packed layout only) + the finish kernel that shades the winners
-// SLOTS: node steps on the 16-byte slot streams (production frames of scenes whose streams are usable), else on the exact records
-template <int FEAT, bool COUNT, bool SLOTS>
+template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
 hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_shadow_wave<FEAT, COUNT, SLOTS>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
+    wf_walk_shadow_wave<FEAT, COUNT>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
     C.flush(counters);
 }
 
-template <int FEAT, bool COUNT, bool SLOTS>
+template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
 hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_closest_wave<FEAT, COUNT, SLOTS>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
+    wf_walk_closest_wave<FEAT, COUNT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
 
@@ -333,9 +332,6 @@ struct DeviceState {
     TlasDevice tl{};                           // device-side TLAS maintenance (hrt_bvh.hpp); aux arrays below
     void* tlaux[10] = {};                      // parent, nchild, arrive, scanIn, scanOut, sa, flags, cost, saBase, scanTmp + costPartial
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
-    void* slotmem[9] = {};                     // slot streams of the walker: top {slots, sizes, off, info}, blas {slots, sizes, off, info}, scan temp
-    SlotStream sTop{}, sBlas{};
-    size_t slotScanBytes = 0;
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     bool tlas_lbvh = false;                    // the TLAS in use was BUILT on the device (Auto rebuilds an uploaded tree once: the LBVH walks faster)
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
@@ -368,7 +364,6 @@ struct hrt_ctx {
     std::string err;
     bool scene_ready = false;
     bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
-    bool slots_ok = false;                     // the walker's slot streams (hrt_bvh.hpp) are usable for the trees in use
     int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
     int wide_depth = 0;                        // > 0: the 4-wide collapse exists; stack bound of the wide walker = 3 * wide_depth + 2
     int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
@@ -506,8 +501,6 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
-    for (int i = 0; i < 9; i++) { if (d.slotmem[i]) (void)hipFree(d.slotmem[i]); d.slotmem[i] = nullptr; }
-    d.sTop = SlotStream{}; d.sBlas = SlotStream{}; d.slotScanBytes = 0;
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
     for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
@@ -1051,50 +1044,6 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nR
     return HRT_OK;
 }
 
-// Slot streams of the persistent walker (hrt_bvh.hpp): allocated per upload, rebuilt on the device whenever the trees change.
-int ensure_slot_memory(hrt_ctx* c, DeviceState& d, int capTop, int capBlas)
-{
-    const size_t scan = (tlas_iscan_temp_bytes(std::max(capTop, capBlas) + 1) + 255) & ~(size_t)255;
-    const size_t bytes[9] = {(size_t)capTop * 2 * sizeof(float4), (size_t)(capTop + 1) * 4, (size_t)(capTop + 1) * 4, 16,
-                             (size_t)capBlas * 2 * sizeof(float4), (size_t)(capBlas + 1) * 4, (size_t)(capBlas + 1) * 4, 16, scan};
-    for (int i = 0; i < 9; i++)
-    {
-        if (d.slotmem[i]) { (void)hipFree(d.slotmem[i]); d.slotmem[i] = nullptr; }
-        HIPCHK(c, hipMalloc(&d.slotmem[i], bytes[i]));
-        HIPCHK(c, hipMemsetAsync(d.slotmem[i], 0, bytes[i], d.stream));
-    }
-    d.sTop = SlotStream{(float4*)d.slotmem[0], (int*)d.slotmem[1], (int*)d.slotmem[2], (int*)d.slotmem[3], capTop};
-    d.sBlas = SlotStream{(float4*)d.slotmem[4], (int*)d.slotmem[5], (int*)d.slotmem[6], (int*)d.slotmem[7], capBlas};
-    d.slotScanBytes = scan;
-    d.dpacked.sTop = d.sTop.slots; d.dpacked.sTopInfo = d.sTop.info;
-    d.dpacked.sBlas = d.sBlas.slots; d.dpacked.sBlasInfo = d.sBlas.info;
-    return HRT_OK;
-}
-
-// (re)builds both streams from the records the walkers would otherwise read; blocks; *usable: every reachable inner node's hit
-// child is its next record (always so for trees numbered in walk order)
-int build_slot_streams(hrt_ctx* c, DeviceState& d, bool* usable)
-{
-    *usable = false;
-    if (!d.slotmem[0] || !c->packed_ok) return HRT_OK;
-    const NodeQ* top = d.dpacked.tlasX ? d.dpacked.tlasX : d.dpacked.tlas;
-    const int nTop = d.dpacked.tlasX ? d.dpacked.nTlasX : d.dpacked.nTlas;
-    const int nB = (int)c->n_blas;
-    if (nTop <= 0 || nTop > d.sTop.cap || nB > d.sBlas.cap) return HRT_OK;
-    HIPCHK(c, slots_build(top, nTop, d.sTop, d.slotmem[8], d.slotScanBytes, d.stream));
-    if (nB > 0)
-    {
-        HIPCHK(c, slots_build(d.dpacked.blas, nB, d.sBlas, d.slotmem[8], d.slotScanBytes, d.stream));
-        HIPCHK(c, slots_patch_finst((FInst*)d.packed[1], (int)c->n_slots, d.sBlas.off, nB, d.stream));
-    }
-    int it[2] = {0, 1}, ib[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(it, d.sTop.info, sizeof(it), hipMemcpyDeviceToHost, d.stream));
-    if (nB > 0) HIPCHK(c, hipMemcpyAsync(ib, d.sBlas.info, sizeof(ib), hipMemcpyDeviceToHost, d.stream));
-    HIPCHK(c, hipStreamSynchronize(d.stream));
-    *usable = it[1] == 0 && ib[1] == 0 && it[0] > 0;
-    return HRT_OK;
-}
-
 template <class TR> struct PackedFeat { static constexpr int value = -1; };
 template <int F> struct PackedFeat<TracerPackedT<F>> { static constexpr int value = F; };
 
@@ -1165,8 +1114,6 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
     static const int wideEnv = HRT_ENV("HRT_WIDE") ? atoi(HRT_ENV("HRT_WIDE")) : 0;
     static const bool forkShadow = HRT_ENV("HRT_NO_FORK") == nullptr;       // A/B knob
-    static const bool noSlots = HRT_ENV("HRT_NO_SLOTS") != nullptr;         // A/B knob: walk the exact records
-    const bool slots = c->slots_ok && !count && !noSlots;                   // 16-byte slot streams (hrt_bvh.hpp)
     static const bool forkStatic = HRT_ENV("HRT_FORK_STATIC") != nullptr;   // A/B knob
 #ifdef HRT_TUNING
     const bool wide = wideEnv > 0 && !count && PackedFeat<TR>::value >= 0 && c->wide_depth > 0 && c->wide_depth <= kWideMaxDepth;
@@ -1199,8 +1146,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 constexpr int F = PackedFeat<TR>::value;
                 if (count)
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
 #ifdef HRT_TUNING
@@ -1217,32 +1164,16 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     // the first one's drain frees, instead of waiting for its last ray
                     HIPCHK(c, hipEventRecord(d.evFork, d.stream));
                     HIPCHK(c, hipStreamWaitEvent(d.stream2, d.evFork, 0));
-                    if (slots)
-                    {
-                        hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, false>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
-                    }
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
                     HIPCHK(c, hipEventRecord(d.evJoin, d.stream2));
                     HIPCHK(c, hipStreamWaitEvent(d.stream, d.evJoin, 0));
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
                 else
                 {
-                    if (slots)
-                    {
-                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                        hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                        hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                    }
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
             }
@@ -1536,13 +1467,6 @@ try {
         d.dpacked.nTlas = (int)ph.tlas.size();
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
-        {
-            int rcS = ensure_slot_memory(c, d, (int)(capT + capTI), (int)std::max<int64_t>(s->n_blasNodes, 1));
-            if (rcS != HRT_OK) return rcS;
-            bool usable = false;
-            if ((rcS = build_slot_streams(c, d, &usable)) != HRT_OK) return rcS;
-            c->slots_ok = (&d == &c->dev[0] ? true : c->slots_ok) && usable;
-        }
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
     }
     c->scene_ready = true;
@@ -1661,12 +1585,6 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         d.dpacked.tlasX = inl ? (const NodeQ*)d.packed[6] : nullptr;
         d.dpacked.nTlasX = inl ? T.nT + T.nTI : 0;
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = kWNone;
-        {   // the walker's slot streams follow every change of the trees (boxes, topology, leaf slots)
-            c->n_tlas = T.nT; c->n_slots = T.nTI;
-            bool usable = false;
-            if ((rc = build_slot_streams(c, d, &usable)) != HRT_OK) return rc;
-            c->slots_ok = (&d == &c->dev[0] ? true : c->slots_ok) && usable;
-        }
         if (first)
         {
             float ms = 0.f;

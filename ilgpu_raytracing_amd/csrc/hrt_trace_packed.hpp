@@ -24,7 +24,6 @@
 // lookups are pure functions of the winner and are evaluated once, after the walk.
 #pragma once
 #include "hrt_device.hpp"
-#include <hip/hip_fp16.h>
 
 namespace hrt {
 
@@ -55,10 +54,6 @@ struct DPacked {
     int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
     const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
-    // slot streams of the persistent walker (hrt_bvh.hpp "node streams"): the TLAS in use (tlasX when built, else tlas) and all BLASes.
-    // info[0] = slots in use.  General leaf slots carry their BLAS' slot range in FInst a.x / a.y.
-    const float4* sTop; const int* sTopInfo;
-    const float4* sBlas; const int* sBlasInfo;
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514
@@ -76,18 +71,6 @@ HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)  
     tmin = hrt_fmax(tmin, hrt_fmin(t1, t2));
     tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
     return tmax >= hrt_fmax(tmin, tMin) && tmin <= tMax;
-}
-// Box test of an inner slot (six half-precision bounds rounded outward, hrt_bvh.hpp): the same slab test on the decoded box.
-// Conservative by monotonicity of the test in the box, which needs finite slab arithmetic: callers route rays with a
-// non-finite origin or 1/d to the exact records.
-HRT_D float half_lo(float packed) { return __half2float(__ushort_as_half((unsigned short)(__float_as_uint(packed) & 0xFFFFu))); }
-HRT_D float half_hi(float packed) { return __half2float(__ushort_as_half((unsigned short)(__float_as_uint(packed) >> 16))); }
-HRT_D bool hit_box_h(const Ray& r, float4 s, float tMin, float tMax)
-{
-    float4 lo, hi;
-    lo.x = half_lo(s.x); lo.y = half_hi(s.x); lo.z = half_lo(s.y); hi.x = half_hi(s.y); hi.y = half_lo(s.z); hi.z = half_hi(s.z);
-    lo.w = hi.w = 0.f;
-    return hit_box(r, lo, hi, tMin, tMax);
 }
 // The world ray is dead weight while a general instance's BLAS is walked with the object-space
 // ray, but it must survive for the rest of the TLAS walk.  hipcc can only spill to scratch

@@ -51,13 +51,9 @@ __device__ unsigned long long g_walk_stats[2][24];
 // lanes, so its lanes stay full until the whole chain has been handed out: a path range that holds only a few live
 // rays (every range does beyond the first bounce) no longer costs a wave of its own.
 // fetch(i, ray, tMax) loads entry i (false: entry carries no ray); done(i, result) consumes its result.
-// SLOTS: node steps read the 16-byte slot streams (half-precision inner nodes, hrt_bvh.hpp) instead of the 32-byte exact
-// records: half the L1 accesses per node.  Same leaves entered in the same order (inner nodes only accelerate); production
-// frames only, the counting build keeps the exact records whose visits it counts.
-template <int FEAT, bool ANY, bool COUNT, bool SLOTS, class NextSeg, class Fetch, class Done>
+template <int FEAT, bool ANY, bool COUNT, class NextSeg, class Fetch, class Done>
 HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
-    static_assert(!(SLOTS && COUNT), "the counting build walks the exact records");
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
     // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
@@ -70,7 +66,6 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
     Tex tex(S);
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int nTopSlots = SLOTS ? P.sTopInfo[0] : 0;
 
 #ifdef HRT_WALK_STATS
     unsigned long long ws[20] = {};     // [12..16] shader-clock cycles in refill / node steps / TLEAF / BLEAF / retire
@@ -113,16 +108,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     {
                         rayIdx = segBase + segCur + rank;
                         bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false;
-                        if (fetch(rayIdx, w, tMaxW))
-                        {
-                            C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS;
-                            if (SLOTS && !finite_ray(w))
-                            {   // outward-rounded inner boxes are only conservative in finite slab arithmetic: this ray walks the exact records, now
-                                if (ANY) occl = tr.template occluded_ext<COUNT, true>(w, tMaxW, C, park_mem);
-                                else tr.template closest_raw<COUNT, true>(w, bestT, bestTObj, bestSlot, bestPrim, C, park_mem);
-                                mode = M_DONE;
-                            }
-                        }
+                        if (fetch(rayIdx, w, tMaxW)) { C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS; }
                         else mode = M_DONE;                   // queue entry without a ray (path already ended)
                     }
                     segCur += nIdle < avail ? nIdle : avail;
@@ -141,38 +127,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             const int nWalk = __popcll(__ballot(walking));
             if (nWalk == 0 || (burst > 0 && nWalk < 24)) break;
             WSTAT(1, 1); WSTAT(2, nWalk);
-            if (SLOTS && walking)
-            {
-                const bool top = !kGeneral || mode == M_TLAS;
-                const float4* S = top ? P.sTop : P.sBlas;
-                const int last = (top ? nTopSlots : blasEnd) - 1;
-                // two consecutive slots leave together: one exact record, or an inner node and what follows it in walk order
-                const float4 sa = S[cur <= last ? cur : last], sb = S[cur + 1 <= last ? cur + 1 : last];
-                __builtin_amdgcn_sched_barrier(0);
-                const float lim = top ? (ANY ? tMaxW : bestT) : (ANY ? tMaxW * iscale : tObj);
-                const int w0 = wbits(sa);
-                const int cnt = (int)((unsigned)w0 >> 28), sk = w0 & kEnd;
-                if (cnt == 0)
-                {
-                    if (!hit_box_h(w, sa, 0.001f, lim)) cur = sk;
-                    else
-                    {
-                        cur = cur + 1;                           // the hit child is the next slot: if it is an inner node too, it is here already
-                        const int w1 = wbits(sb);
-                        if (((unsigned)w1 >> 28) == 0 && cur <= last) { if (!hit_box_h(w, sb, 0.001f, lim)) cur = w1 & kEnd; else cur = cur + 1; }
-                    }
-                }
-                else
-                {
-                    const bool isInst = inl && cnt == 15;        // the one-node BLAS of an instance (its box test takes tMax, not the closest t)
-                    if (!hit_box(w, sa, sb, 0.001f, isInst ? (ANY ? tMaxW : 1e30f) : lim)) cur = sk;
-                    else if (isInst) { li = wbits(sb); lskip = sk; mode = M_TLEAF; }
-                    else if (inl) cur = cur + 2;                 // its instance records follow
-                    else if (top) { li = wbits(sb); lend = li + cnt; lskip = sk; mode = M_TLEAF; }
-                    else          { bj = wbits(sb); bend = bj + cnt; bskip = sk; mode = M_BLEAF; }
-                }
-            }
-            if (!SLOTS && walking)
+            if (walking)
             {
                 const bool top = !kGeneral || mode == M_TLAS;
                 const NodeQ* nodes = top ? (inl ? P.tlasX : P.tlas) : P.blas;
@@ -274,7 +229,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             else
             {   // general instance: park the world ray, walk its BLAS with the object-space ray
                 islot = li; iflags = flags; iscale = f.c.z;
-                cur = __float_as_int(SLOTS ? f.a.x : f.c.x); blasEnd = __float_as_int(SLOTS ? f.a.y : f.c.y);      // node range of the BLAS, in slots or records
+                cur = __float_as_int(f.c.x); blasEnd = __float_as_int(f.c.y);
                 tObj = 1e30f; iprim = -1;
                 park.put(w);
                 w = tr.object_ray(w, flags, wbits(f.b));
