@@ -125,21 +125,14 @@ __device__ __forceinline__ int wf_range(int nRanges)
     return range < nRanges ? range : -1;
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(256)
-hrt_wf_init_kernel(FrameK k, WfGeom g, DGBuffer gb, WfBuffers W)
-{
-    int range = wf_range(W.nRanges);
-    wf_init_wave<COUNT>(k, g, gb, W, range);      // every wave takes part in the workgroup's packing
-}
-
-template <bool COUNT>
+// FIRST: depth 0, vertices straight from the G-buffer (every wave takes part in the workgroup's packing of the live paths)
+template <bool COUNT, bool FIRST>
 __global__ void __launch_bounds__(256)
 hrt_wf_shade_kernel(FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long long nPix, WfBuffers W, int vsel, int depth, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int range = wf_range(W.nRanges);
-    if (range >= 0) wf_shade_wave<COUNT>(k, g, gb, resPrev, nPix, W, vsel ? W.B : W.A, depth, range, C);
+    if (FIRST || range >= 0) wf_shade_wave<COUNT, FIRST>(k, g, gb, resPrev, nPix, W, vsel ? W.B : W.A, depth, range, C);
     C.flush(counters);
 }
 
@@ -190,14 +183,15 @@ hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int dep
     C.flush(counters);
 }
 
-template <int FEAT, bool COUNT>
+// EXISTS: the closest-hit walk of the last bounce, where only hit-or-miss is used (hrt_walker.hpp)
+template <int FEAT, bool COUNT, bool EXISTS = false>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
 hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_closest_wave<FEAT, COUNT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
+    wf_walk_closest_wave<FEAT, COUNT, EXISTS>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
 
@@ -1133,14 +1127,22 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
         g.batchStart = b0;
         g.batchCount = (int)std::min<long long>(sb, spp - b0);
         g.lastBatch = (b0 + g.batchCount >= spp) ? 1 : 0;
-        if (count) hipLaunchKernelGGL((hrt_wf_init_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, W);
-        else       hipLaunchKernelGGL((hrt_wf_init_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, W);
         for (int depth = 0; depth < k.maxDepth; depth++)
         {
             const int vsel = depth & 1;
+#ifdef HRT_NO_EXISTS            // A/B
+            const bool lastBounce = false;
+#else
+            const bool lastBounce = depth + 1 >= k.maxDepth;        // its closest-hit walk only decides hit or miss
+#endif
             const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0 || wide) ? 1 : 0;      // the wide walker's overflow area is sized for the persistent grid
-            if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
-            else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            if (depth == 0)
+            {
+                if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false, true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            }
+            else if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            else            hipLaunchKernelGGL((hrt_wf_shade_kernel<false, false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             if constexpr (PackedFeat<TR>::value >= 0)
             {   // packed layout: persistent-wave walks + finish
                 constexpr int F = PackedFeat<TR>::value;
@@ -1164,7 +1166,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     // the first one's drain frees, instead of waiting for its last ray
                     HIPCHK(c, hipEventRecord(d.evFork, d.stream));
                     HIPCHK(c, hipStreamWaitEvent(d.stream2, d.evFork, 0));
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    if (lastBounce) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
                     HIPCHK(c, hipEventRecord(d.evJoin, d.stream2));
                     HIPCHK(c, hipStreamWaitEvent(d.stream, d.evJoin, 0));
@@ -1173,7 +1176,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 else
                 {
                     hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    if (lastBounce) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
             }

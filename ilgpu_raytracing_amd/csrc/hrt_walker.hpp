@@ -51,9 +51,13 @@ __device__ unsigned long long g_walk_stats[2][24];
 // lanes, so its lanes stay full until the whole chain has been handed out: a path range that holds only a few live
 // rays (every range does beyond the first bounce) no longer costs a wave of its own.
 // fetch(i, ray, tMax) loads entry i (false: entry carries no ray); done(i, result) consumes its result.
-template <int FEAT, bool ANY, bool COUNT, class NextSeg, class Fetch, class Done>
+// EXISTS (closest-hit walks of the LAST bounce, production frames): only whether TraceClosest finds a hit is used there
+// (a miss adds the sky, a hit ends the path: RTRay.cs:241-243, 298-305), so the walk stops at the first hit it accepts -- the
+// same tests with the same limits in the same order up to that point, hence the same answer to "is best.t < 1e29".
+template <int FEAT, bool ANY, bool COUNT, bool EXISTS, class NextSeg, class Fetch, class Done>
 HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
+    static_assert(!(EXISTS && (ANY || COUNT)), "EXISTS is a closest-hit walk of a production frame");
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
     // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
@@ -201,7 +205,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
             if (hit_sphere_t(w, xyz(fc), fc.w, t) && t > 0.001f && t < lim)
             {
                 if (ANY) { occl = true; mode = M_DONE; }
-                else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); }
+                else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); if (EXISTS) mode = M_DONE; }
             }
             if (mode == M_TLEAF) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
         }
@@ -221,7 +225,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     if (hit_sphere_t(w, xyz(f.c), f.c.w, t) && t > 0.001f && t < lim)
                     {
                         if (ANY) { occl = true; mode = M_DONE; }
-                        else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); }
+                        else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); if (EXISTS) mode = M_DONE; }
                     }
                 }
                 li++;
@@ -255,6 +259,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                 {
                     if (ANY) { occl = true; mode = M_DONE; }
                     else { tObj = t; iprim = p; }
+                    if (EXISTS && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }   // what the fold at the end of this BLAS would accept (:65-77)
                 }
             }
             else
@@ -285,6 +290,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                                 accept = !(alpha < mat->AlphaCutoff);
                             }
                             if (accept) { tObj = t; iprim = bj; }
+                            if (EXISTS && accept && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }
                         }
                     }
                     else if (!(t <= 0.001f || t >= lim))

@@ -16,7 +16,7 @@
 //     wf_shadow  (walk)    any-hit; unoccluded -> Li += T * direct
 //     wf_closest (walk)    closest hit -> next vertex, or Li += T * sky and the path ends
 //
-// between wf_init (paths from the G-buffer) and wf_resolve (ordered per-pixel sum over samples,
+// between the depth-0 form of wf_shade (paths start from the G-buffer) and wf_resolve (ordered per-pixel sum over samples,
 // reservoir hand-off, framebuffer store).  Samples of a pixel run concurrently; the only
 // cross-sample orderings of the reference are reproduced explicitly: Lframe is summed in sample
 // order by wf_resolve, and resCur receives the reservoir of the LAST sample that reached a
@@ -111,86 +111,57 @@ HRT_D int wave_prefix(bool keep, int& total)
     return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
 }
 
-// ------------------------------------------------------------------ init: G-buffer -> depth-0 vertices
-template <bool COUNT>
-HRT_D void wf_init_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const WfBuffers& W, int range)
-{
-    // live paths of the four ranges of a workgroup are packed together, as in wf_finish_wave
-    __shared__ int s_cnt[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long base = (long long)range * kRange;
-    const long long nPaths = (long long)g.batchCount * g.nOrd;
-    int mine = 0;
-    if (range >= 0)
-        for (int it = 0; it < kRange / 64; it++)
-        {
-            const long long pid = base + it * 64 + lane;
-            bool live = false;
-            if (pid < nPaths)
-            {
-                const int s = (int)(pid / g.nOrd);
-                int x, y;
-                if (ord_pixel(g, k, (int)(pid - (long long)s * g.nOrd), x, y)) live = gb.hitMask[y * k.width + x] != 0;
-            }
-            mine += __popcll(__ballot(live));
-        }
-    if (lane == 0) s_cnt[wv] = mine;
-    __syncthreads();
-    int before = 0, groupTotal = 0;
-    for (int j = 0; j < 4; j++) { const int cj = s_cnt[j]; if (j < wv) before += cj; groupTotal += cj; }
-    if (range < 0) return;
-    const int groupRange = range & ~3;
-    const long long groupBase = (long long)groupRange * kRange;
-    int outCount = before;
-    for (int it = 0; it < kRange / 64; it++)
-    {
-        long long pid = base + it * 64 + lane;
-        bool live = false;
-        int index = 0, x = 0, y = 0, s = 0;
-        if (pid < nPaths)
-        {
-            s = (int)(pid / g.nOrd);
-            int ord = (int)(pid - (long long)s * g.nOrd);
-            if (ord_pixel(g, k, ord, x, y))
-            {
-                index = y * k.width + x;
-                live = gb.hitMask[index] != 0;
-            }
-            W.sampleLi.st3(0, pid, mk3(0.f, 0.f, 0.f));      // maxDepth == 0 leaves Li = 0 (RTRay.cs:228)
-            W.stage.sti(G_FLAG, pid, 0);
-        }
-        int total;
-        int off = wave_prefix(live, total);
-        if (live)
-        {
-            long long slot = groupBase + outCount + off;
-            const F3 gpos = ld3(&gb.worldPos[index]);
-            const int packedMat = gb.matId[index];
-            W.A.st3(V_POS, slot, gpos);
-            W.A.st3(V_NRM, slot, normalize(ld3(&gb.normalWS[index])));            // :222
-            W.A.st3(V_ALB, slot, ld3(&gb.baseColor[index]));
-            W.A.st3(V_IDIR, slot, normalize(gpos - cv3(k.cam.origin)));           // ViewDirFromCam :230
-            W.A.st3(V_T, slot, mk3(1.f, 1.f, 1.f));
-            W.A.st3(V_LI, slot, mk3(0.f, 0.f, 0.f));
-            SeedBase sb = seed_base((uint32_t)(index % hrt_imax(1, k.width)), (uint32_t)(index / hrt_imax(1, k.width)), k.frame, 0xC0FFEEu, k.rngLockNoise);
-            W.A.sti(V_RNG, slot, (int)rng_for_sample(sb, (uint32_t)(g.batchStart + s)).s);
-            W.A.sti(V_PID, slot, (int)pid);
-            W.A.sti(V_MAT, slot, packedMat & 0xFFFF);
-            W.A.stf(V_IOR, slot, (float)((packedMat >> 16) & 0xFFFF) / 1000.f);   // I16ToFloat :226
-        }
-        outCount += total;
-    }
-    if (lane == 0) W.cntA[range] = max(0, min(kRange, groupTotal - (range - groupRange) * kRange));
-}
-
 // ------------------------------------------------------------------ shade: vertex -> ray requests (RTRay.cs:235-312)
-template <bool COUNT>
+// FIRST (depth 0): the vertices are the G-buffer's (RTRay.cs:212-231) and are never written out as path state.  The four
+// waves of a workgroup own four consecutive ranges; the live paths (pixels with a primary hit) of those 4 x kRange path ids are
+// packed together into the front of the group, as wf_finish_wave packs survivors: pass 1 lists them in LDS by rank (ballot
+// prefixes + one block-wide offset), pass 2 lets lane l of iteration t of wave j shade rank j kRange + 64 t + l at its own slot.
+// Only what the later kernels read of a vertex that was never stored goes to the vertex planes: V_PID and V_LI = 0.
+template <bool COUNT, bool FIRST>
 HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const DReservoir& resPrev, long long nPix,
                          const WfBuffers& W, const Planes& V, int depth, int range, Cnt<COUNT>& C)
 {
     const int lane = threadIdx.x & 63;
     const long long base = (long long)range * kRange;
-    const int n = W.cntA[depth * W.nRanges + range];
+    __shared__ int s_first_cnt[FIRST ? 4 : 1];
+    __shared__ int s_first_pid[FIRST ? 4 * kRange : 1];
+    int n;
+    if (FIRST)
+    {
+        const int wv = threadIdx.x >> 6;
+        const long long nPaths = (long long)g.batchCount * g.nOrd;
+        auto live_at = [&](long long pid) -> bool {
+            if (pid >= nPaths) return false;
+            const int p32 = (int)pid, s = p32 / g.nOrd;                   // a sample batch holds at most 2^25 paths
+            int x, y;
+            return ord_pixel(g, k, p32 - s * g.nOrd, x, y) && gb.hitMask[y * k.width + x] != 0;
+        };
+        int mine = 0;
+        if (range >= 0)
+            for (int it = 0; it < kRange / 64; it++) mine += __popcll(__ballot(live_at(base + it * 64 + lane)));
+        if (lane == 0) s_first_cnt[wv] = mine;
+        __syncthreads();
+        int before = 0, groupTotal = 0;
+        for (int j = 0; j < 4; j++) { const int cj = s_first_cnt[j]; if (j < wv) before += cj; groupTotal += cj; }
+        if (range >= 0)
+        {
+            int at = before;
+            for (int it = 0; it < kRange / 64; it++)
+            {
+                const long long pid = base + it * 64 + lane;
+                const bool live = live_at(pid);
+                int total;
+                const int off = wave_prefix(live, total);
+                if (live) s_first_pid[at + off] = (int)pid;
+                at += total;
+            }
+        }
+        __syncthreads();
+        if (range < 0) return;
+        n = max(0, min(kRange, groupTotal - (range & 3) * kRange));
+        if (lane == 0) W.cntA[range] = n;
+    }
+    else n = W.cntA[depth * W.nRanges + range];
     int sqCount = 0;
     for (int it = 0; it * 64 < n; it++)
     {
@@ -204,10 +175,34 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
         Ray ray; ray.o = so; ray.d = so;
         if (valid)
         {
-            const F3 pos = V.ld3(V_POS, slot), nrm = V.ld3(V_NRM, slot), alb = V.ld3(V_ALB, slot), I = V.ld3(V_IDIR, slot);
-            T = V.ld3(V_T, slot);
-            rng.s = (uint32_t)V.ldi(V_RNG, slot);
-            const int mat = V.ldi(V_MAT, slot);
+            F3 pos, nrm, alb, I; int mat; int pid0 = 0, index0 = 0; float ior0 = 0.f;
+            if (FIRST)
+            {   // the G-buffer vertex every sample starts from (:221-230)
+                pid0 = s_first_pid[(range & 3) * kRange + i];
+                const int s0 = pid0 / g.nOrd;
+                int x, y;
+                ord_pixel(g, k, pid0 - s0 * g.nOrd, x, y);
+                index0 = y * k.width + x;
+                pos = ld3(&gb.worldPos[index0]);
+                nrm = normalize(ld3(&gb.normalWS[index0]));                   // :222
+                alb = ld3(&gb.baseColor[index0]);
+                I = normalize(pos - cv3(k.cam.origin));                        // ViewDirFromCam :230
+                T = mk3(1.f, 1.f, 1.f);
+                const SeedBase sb = seed_base((uint32_t)(index0 % hrt_imax(1, k.width)), (uint32_t)(index0 / hrt_imax(1, k.width)), k.frame, 0xC0FFEEu, k.rngLockNoise);
+                rng = rng_for_sample(sb, (uint32_t)(g.batchStart + s0));
+                const int packedMat = gb.matId[index0];
+                mat = packedMat & 0xFFFF;
+                ior0 = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;          // I16ToFloat :226
+                V.sti(V_PID, slot, pid0);
+                V.st3(V_LI, slot, mk3(0.f, 0.f, 0.f));
+            }
+            else
+            {
+                pos = V.ld3(V_POS, slot); nrm = V.ld3(V_NRM, slot); alb = V.ld3(V_ALB, slot); I = V.ld3(V_IDIR, slot);
+                T = V.ld3(V_T, slot);
+                rng.s = (uint32_t)V.ldi(V_RNG, slot);
+                mat = V.ldi(V_MAT, slot);
+            }
             const int shade = mat & 0xFFFF;
             flg = (mat >> 16) & RF_WROTE;
             if (shade == HRT_SHADING_MIRROR)
@@ -218,7 +213,7 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
             }
             else if (shade == HRT_SHADING_GLASS)
             {   // :246-275
-                const float ior = V.ldf(V_IOR, slot);
+                const float ior = FIRST ? ior0 : V.ldf(V_IOR, slot);
                 F3 Nuse = nrm;
                 bool outside = dot(I, nrm) < 0.f;
                 if (!outside) Nuse = Nuse * -1.f;
@@ -250,11 +245,15 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
             }
             else
             {   // :277-317
-                const int pid = V.ldi(V_PID, slot);
-                const int ord = pid % g.nOrd;
-                int x, y;
-                ord_pixel(g, k, ord, x, y);
-                const int index = y * k.width + x;
+                int pid, index;
+                if (FIRST) { pid = pid0; index = index0; }
+                else
+                {
+                    pid = V.ldi(V_PID, slot);
+                    int x, y;
+                    ord_pixel(g, k, pid % g.nOrd, x, y);
+                    index = y * k.width + x;
+                }
                 Frame fr = make_frame(nrm);
                 Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !(flg & RF_WROTE), pos, fr, alb, rng, C);
                 if (r.m > 0 && r.wSum > 0.f && r.w > 0.f)
@@ -307,6 +306,7 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
             W.SQ.sti(S_VIS, q, 0);
             flg |= RF_SHADOW | ((sqCount + off) << 8);        // wf_finish adds the direct light if the walk leaves S_VIS set
         }
+        if (FIRST && valid && !(flg & RF_WROTE)) W.stage.sti(G_FLAG, s_first_pid[(range & 3) * kRange + i], 0);     // no reservoir from this sample yet
         if (valid)
         {
             W.R.st4(RQ_A, slot, mkq(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
@@ -433,7 +433,7 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntS + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, true, COUNT>(tr,
+    walk_queue<FEAT, true, COUNT, false>(tr,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int q, Ray& r, float& tMax) {
             const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
@@ -444,12 +444,12 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W
         }, C);
 }
 
-template <int FEAT, bool COUNT>
+template <int FEAT, bool COUNT, bool EXISTS>
 HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntA + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, false, COUNT>(tr,
+    walk_queue<FEAT, false, COUNT, EXISTS>(tr,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int slot, Ray& r, float& tMax) {
             tMax = 1e30f;
@@ -618,7 +618,8 @@ HRT_D void wf_resolve_pixel(const FrameK& k, const WfGeom& g, const DGBuffer& gb
         for (int s = 0; s < g.batchCount; s++)
         {
             long long pid = (long long)s * g.nOrd + ord;
-            Lframe = Lframe + safe_color(W.sampleLi.ld3(0, pid));             // :320, in sample order
+            if (k.maxDepth <= 0) continue;                                     // no bounce loop: Li = 0 (:228), nothing was staged
+            Lframe = Lframe + safe_color(W.sampleLi.ld3(0, pid));             // :320, in sample order; every live path stores its Li exactly once, where it ends
             if (W.stage.ldi(G_FLAG, pid)) winner = s;                          // last sample that reached a diffuse vertex
         }
         if (winner >= 0)
