@@ -368,7 +368,7 @@ def roofline_of(res, pmc, pmc_src, world):
     """VALU-issue roofline of the path-trace stage + its measured HBM picture (see the module docstring)."""
     cfg = res["cfg"]
     kernel = ("hrt_path_trace_kernel<TracerFlat> (fused; sample-group split kernel + resolve on small tiles)" if res["fused"]
-              else "path-trace stage, streamed: hrt_wf_{init,shade,walk_shadow,walk_closest,finish,resolve}_kernel")
+              else "path-trace stage, streamed: hrt_wf_{shade,walk_shadow,walk_closest,finish,resolve}_kernel")
     launch_s = res["path_ms"] * 1e-3
     compulsory = res["pixels"] * (48 + 12 + 44)      # G-buffer read 48 B + framebuffer write 12 B + reservoir write <= 44 B per pixel
     out = {"bound": "valu", "kernel": kernel, "launch_ms": round(res["path_ms"], 4),

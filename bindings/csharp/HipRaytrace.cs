@@ -96,6 +96,12 @@ namespace ILGPU_Raytracing.Engine
         [DllImport(Lib)] public static extern int hrt_present(IntPtr ctx, HrtPresentParams* p, int* outColorHost);
         [DllImport(Lib)] public static extern int hrt_synchronize(IntPtr ctx, HrtStats* stats);
         [DllImport(Lib)] public static extern int hrt_reset_history(IntPtr ctx);
+        // page-lock the managed framebuffer arrays once (GCHandle.Alloc(array, GCHandleType.Pinned).AddrOfPinnedObject()): gathers
+        // into them become asynchronous DMA; keep the handles alive until hrt_host_unregister / hrt_destroy
+        [DllImport(Lib)] public static extern int hrt_host_register(IntPtr ctx, void* ptr, long bytes);
+        [DllImport(Lib)] public static extern int hrt_host_unregister(IntPtr ctx, void* ptr);
+        [DllImport(Lib)] public static extern int hrt_frame_times(IntPtr ctx, int dev, int launch, float* ms, int cap, int* n);
+        [DllImport(Lib)] public static extern int hrt_set_workspace_limit(IntPtr ctx, long maxResidentPaths);
         [DllImport(Lib)] public static extern int hrt_device_count();
 
         // native asset loader (optional: a C# host may keep MeshLoaderOBJ)

@@ -24,5 +24,16 @@ if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
   tail -5 $OUT/bench.err | tee -a $OUT/progress.log
   echo "== rocprofv3 kernel stats of the bench command (config 2 only, no PMC child, no extras)" | tee -a $OUT/progress.log
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c2 -- python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --pmc off --extras 0 > $OUT/prof_bench_c2.json 2> $OUT/prof_c2.err; echo "rocprof rc=$?" | tee -a $OUT/progress.log
-  python tools/kstats.py $OUT/prof_c2 | head -8 | tee -a $OUT/progress.log
+  python tools/kstats.py $OUT/prof_c2 8 | tee -a $OUT/progress.log
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = configs ]; then
+  for spec in "3:0" "4:4"; do
+    c=${spec%%:*}; spp=${spec#*:}; SPP=""; [ "$spp" != 0 ] && SPP="--spp $spp"
+    echo "== bench config $c $SPP (+ --save-pmc)" | tee -a $OUT/progress.log
+    timeout -k 10 600 python bench.py --config $c $SPP --steps 20 --warmup 3 --cpu-seconds 0 --save-pmc $OUT/pmc_config$c.json > $OUT/bench_c$c.json 2> $OUT/bench_c$c.err; echo "bench rc=$?" | tee -a $OUT/progress.log
+    cut -c1-1500 $OUT/bench_c$c.json | tee -a $OUT/progress.log
+    echo "== rocprofv3 kernel stats config $c" | tee -a $OUT/progress.log
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c$c -- python bench.py --config $c $SPP --steps 10 --warmup 2 --cpu-seconds 0 --pmc off > $OUT/prof_bench_c$c.json 2> $OUT/prof_c$c.err; echo "rocprof rc=$?" | tee -a $OUT/progress.log
+    python tools/kstats.py $OUT/prof_c$c 12 | tee -a $OUT/progress.log
+  done
 fi
