@@ -584,13 +584,14 @@ struct TracerFlat {
     HRT_D bool occluded(const Ray& wray, float tMaxWorld, Cnt<COUNT>& C) const
     {
         if (COUNT || !finite_ray(wray)) return tree.template occluded<COUNT>(wray, tMaxWorld, C);
+        // An any-hit query is an OR over the instances whose sphere test the walk reaches, and by the lemma above the walk reaches
+        // an instance iff the instance's OWN box test passes (tMax is fixed here, and a box that contains the instance's can only
+        // turn a miss into a hit): the leaf boxes decide nothing, so they are not tested, and the order is free.
         bool hit = false;
         const float a = dot(wray.d, wray.d);
         for (int l = 0; l < nLeaves; l++)
         {
             const NodeQ n = leaves[l];
-            PSTAT(15);
-            if (hit || !hit_box(wray, n.lo, n.hi, 0.001f, tMaxWorld)) continue;
             const int first = wbits(n.lo), cnt = (int)((unsigned)wbits(n.hi) >> 28);
             for (int i = first; i < first + cnt; i++)
             {
