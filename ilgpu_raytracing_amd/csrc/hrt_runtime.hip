@@ -172,26 +172,28 @@ hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigne
 }
 
 // persistent-wave walk kernels (packed layout only) + the finish kernel that shades the winners
-template <int FEAT, bool COUNT>
+// ALT: `tr` walks the device-built tree over the same fast-sphere instances (boolean queries do not depend on the tree,
+// hrt_walker.hpp); `exact` is the uploaded tree, for rays whose slab arithmetic is not finite
+template <int FEAT, bool COUNT, bool ALT = false>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
-hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained, unsigned long long* counters)
+hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, WfBuffers W, int vsel, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_shadow_wave<FEAT, COUNT>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
+    wf_walk_shadow_wave<FEAT, COUNT, ALT>(tr, exact, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
     C.flush(counters);
 }
 
 // EXISTS: the closest-hit walk of the last bounce, where only hit-or-miss is used (hrt_walker.hpp)
-template <int FEAT, bool COUNT, bool EXISTS = false>
+template <int FEAT, bool COUNT, bool EXISTS = false, bool ALT = false>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
-hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained, unsigned long long* counters)
+hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, WfBuffers W, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_closest_wave<FEAT, COUNT, EXISTS>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
+    wf_walk_closest_wave<FEAT, COUNT, EXISTS, ALT>(tr, exact, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
 
@@ -326,6 +328,11 @@ struct DeviceState {
     TlasDevice tl{};                           // device-side TLAS maintenance (hrt_bvh.hpp); aux arrays below
     void* tlaux[10] = {};                      // parent, nchild, arrive, scanIn, scanOut, sa, flags, cost, saBase, scanTmp + costPartial
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
+    // a second tree over the same instances, built on the device at upload: what boolean queries of fast-sphere scenes walk
+    TlasDevice tl2{};
+    void* tl2mem[14] = {};
+    DPacked dpackedAny{};
+    bool any_ok = false;
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
     bool tlas_lbvh = false;                    // the TLAS in use was BUILT on the device (Auto rebuilds an uploaded tree once: the LBVH walks faster)
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
@@ -495,6 +502,8 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
+    for (int i = 0; i < 14; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+    d.tl2 = TlasDevice{}; d.any_ok = false;
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
     for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
@@ -1146,10 +1155,33 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
             if constexpr (PackedFeat<TR>::value >= 0)
             {   // packed layout: persistent-wave walks + finish
                 constexpr int F = PackedFeat<TR>::value;
+                // production walks.  Boolean queries (shadow rays, the last bounce's hit-or-miss) of fast-sphere scenes walk the
+                // device-built tree over the same instances when one was made at upload (hrt_walker.hpp, ALT)
+                auto launch_shadow = [&](hipStream_t st) {
+                    if constexpr (F == 0)
+                        if (d.any_ok)
+                        {
+                            TR trAny = tr; trAny.P = d.dpackedAny;
+                            hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, vsel, depth, chained, cnt1);
+                            return;
+                        }
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, vsel, depth, chained, cnt1);
+                };
+                auto launch_closest = [&](hipStream_t st) {
+                    if (!lastBounce) { hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1); return; }
+                    if constexpr (F == 0)
+                        if (d.any_ok)
+                        {
+                            TR trAny = tr; trAny.P = d.dpackedAny;
+                            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, depth, chained, cnt1);
+                            return;
+                        }
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
+                };
                 if (count)
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
 #ifdef HRT_TUNING
@@ -1166,18 +1198,16 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     // the first one's drain frees, instead of waiting for its last ray
                     HIPCHK(c, hipEventRecord(d.evFork, d.stream));
                     HIPCHK(c, hipStreamWaitEvent(d.stream2, d.evFork, 0));
-                    if (lastBounce) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                    else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream2, tr, W, vsel, depth, chained, cnt1);
+                    launch_closest(d.stream);
+                    launch_shadow(d.stream2);
                     HIPCHK(c, hipEventRecord(d.evJoin, d.stream2));
                     HIPCHK(c, hipStreamWaitEvent(d.stream, d.evJoin, 0));
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained, cnt1);
-                    if (lastBounce) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
-                    else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained, cnt1);
+                    launch_shadow(d.stream);
+                    launch_closest(d.stream);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
                 }
             }
@@ -1200,6 +1230,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     }
     return HRT_OK;
 }
+
+int build_boolean_query_tree(hrt_ctx* c, DeviceState& d);       // defined with the scene-update code below
 
 } // namespace
 
@@ -1472,6 +1504,7 @@ try {
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
+        if (int rcB = build_boolean_query_tree(c, d)) return rcB;
     }
     c->scene_ready = true;
     return HRT_OK;
@@ -1501,6 +1534,52 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
     T.lstart = (int*)take((n + 1) * 4); T.lsum = (int*)take((n + 1) * 4); T.leafCounts = (int*)take(16 * 4);
     T.iscanTmp = take(iscanBytes); T.iscanTmpBytes = iscanBytes;
     T.sortTmp = take(sortBytes); T.sortTmpBytes = sortBytes;
+    return HRT_OK;
+}
+
+// Scenes made of many fast-sphere instances (identity transform, one sphere): a second TLAS over the same instances, built on
+// the device with the LBVH of the scene updates, for the queries whose answer does not depend on the tree -- any-hit walks and
+// the last bounce's hit-or-miss walk (hrt_walker.hpp, ALT).  The reference's median split cuts such a scene into slabs when one
+// instance dominates the bounds (the ground sphere of BASELINE config 3: 103 node visits per ray against 50); the
+// closest-hit walks of the other bounces keep the uploaded tree, whose order decides ties.  Dropped again by the first scene
+// update (the tree in use is then device-built anyway, or its boxes have moved).
+constexpr int64_t kAnyTreeMinInstances = 256;
+int build_boolean_query_tree(hrt_ctx* c, DeviceState& d)
+{
+    d.any_ok = false;
+#ifdef HRT_NO_ANY_TREE             // A/B
+    return HRT_OK;
+#endif
+    if (!c->packed_ok || c->packed_feat != 0 || c->n_inst < kAnyTreeMinInstances || !d.dpacked.tlasX) return HRT_OK;
+    int rc = ensure_lbvh_scratch(c, d);
+    if (rc != HRT_OK) return rc;
+    TlasDevice T = d.tl;                                        // inputs, capacities, temporaries and LBVH scratch are shared; outputs are its own
+    const size_t capT = (size_t)T.capT, capTI = (size_t)T.capTI;
+    const size_t bytes[14] = {capT * sizeof(hrt_bvh_node), capTI * 4, capT * sizeof(NodeQ), capTI * sizeof(FInst), (capT + capTI) * sizeof(NodeQ),
+                              (size_t)kFlatMaxLeaves * sizeof(NodeQ), capT * 4, capT * 4, capT * 4, capT * 8, capT * 8, capT * 4, capT * 4, 32};
+    for (int i = 0; i < 14; i++)
+    {
+        if (d.tl2mem[i]) { (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+        HIPCHK(c, hipMalloc(&d.tl2mem[i], bytes[i]));
+        HIPCHK(c, hipMemsetAsync(d.tl2mem[i], 0, bytes[i], d.stream));
+    }
+    T.tlasNodes = (hrt_bvh_node*)d.tl2mem[0]; T.tlasInst = (int32_t*)d.tl2mem[1]; T.tlas = (NodeQ*)d.tl2mem[2]; T.finst = (FInst*)d.tl2mem[3];
+    T.tlasX = (NodeQ*)d.tl2mem[4]; T.flat = (NodeQ*)d.tl2mem[5]; T.parent = (int*)d.tl2mem[6]; T.nchild = (int*)d.tl2mem[7]; T.arrive = (int*)d.tl2mem[8];
+    T.scanIn = (unsigned long long*)d.tl2mem[9]; T.scanOut = (unsigned long long*)d.tl2mem[10]; T.sa = (float*)d.tl2mem[11]; T.saBase = (float*)d.tl2mem[12];
+    T.flags = (int*)d.tl2mem[13]; T.cost = (float*)((char*)d.tl2mem[13] + 16);
+    int leaves = 0;
+    HIPCHK(c, tlas_rebuild_topology(T, d.stream, &leaves));
+    T.directMax = 63;                                           // emitted in walk order
+    HIPCHK(c, tlas_finish(T, d.stream));
+    int flags[4] = {1, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(flags, T.flags, sizeof(flags), hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(c, hipStreamSynchronize(d.stream));
+    if (flags[0] != 0 || leaves <= 0 || (int64_t)T.nT + T.nTI >= kEnd) return HRT_OK;      // an instance that is not a fast sphere after all
+    d.tl2 = T;
+    d.dpackedAny = d.dpacked;
+    d.dpackedAny.tlas = T.tlas; d.dpackedAny.finst = T.finst; d.dpackedAny.nTlas = T.nT;
+    d.dpackedAny.tlasX = T.tlasX; d.dpackedAny.nTlasX = T.nT + T.nTI;
+    d.any_ok = true;
     return HRT_OK;
 }
 
@@ -1551,6 +1630,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             HIPCHK(c, tlas_finish(T, d.stream));
             if ((rc = keep_as_base()) != HRT_OK) return rc;
         }
+        d.any_ok = false;                      // the second tree of boolean queries describes the scene as uploaded
         std::vector<void*> staged;
         struct StagedGuard {               // staging buffers of `mutate` are freed on every way out (their copies are ordered on d.stream)
             std::vector<void*>& v; hipStream_t st;

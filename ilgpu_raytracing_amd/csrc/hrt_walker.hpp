@@ -54,10 +54,17 @@ __device__ unsigned long long g_walk_stats[2][24];
 // EXISTS (closest-hit walks of the LAST bounce, production frames): only whether TraceClosest finds a hit is used there
 // (a miss adds the sky, a hit ends the path: RTRay.cs:241-243, 298-305), so the walk stops at the first hit it accepts -- the
 // same tests with the same limits in the same order up to that point, hence the same answer to "is best.t < 1e29".
-template <int FEAT, bool ANY, bool COUNT, bool EXISTS, class NextSeg, class Fetch, class Done>
-HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
+// ALT (any-hit and hit-or-miss walks of scenes made of fast-sphere instances, production frames): `tr` walks ANOTHER tree over the
+// same instances (the device-built TLAS, hrt_bvh.hpp) than the one the scene was uploaded with.  Exact: such a query is an OR over
+// the instances whose sphere test the walk reaches; the walk reaches an instance iff the instance's OWN box test passes (limits
+// are fixed, every box above it contains it exactly, and enlarging a box can only turn a miss into a hit: DESIGN.md 4), so the
+// tree above the instances decides nothing.  The argument needs finite slab arithmetic: a ray with a non-finite origin or 1/d
+// walks the uploaded tree (`exact`) when it is fetched.
+template <int FEAT, bool ANY, bool COUNT, bool EXISTS, bool ALT, class NextSeg, class Fetch, class Done>
+HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
     static_assert(!(EXISTS && (ANY || COUNT)), "EXISTS is a closest-hit walk of a production frame");
+    static_assert(!ALT || ((ANY || EXISTS) && !COUNT && FEAT == 0), "another tree only for boolean queries over fast-sphere instances");
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
     // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
@@ -112,7 +119,16 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, NextSeg nextSeg, Fetch fetc
                     {
                         rayIdx = segBase + segCur + rank;
                         bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false;
-                        if (fetch(rayIdx, w, tMaxW)) { C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS; }
+                        if (fetch(rayIdx, w, tMaxW))
+                        {
+                            C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS;
+                            if (ALT && !finite_ray(w))
+                            {   // the tree-independence argument needs finite slab arithmetic: this ray walks the uploaded tree, now
+                                if (ANY) occl = exact.template occluded_ext<COUNT, true>(w, tMaxW, C, park_mem);
+                                else exact.template closest_raw<COUNT, true>(w, bestT, bestTObj, bestSlot, bestPrim, C, park_mem);
+                                mode = M_DONE;
+                            }
+                        }
                         else mode = M_DONE;                   // queue entry without a ray (path already ended)
                     }
                     segCur += nIdle < avail ? nIdle : avail;

@@ -428,12 +428,12 @@ struct RangeGrab {
     }
 };
 
-template <int FEAT, bool COUNT>
-HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
+template <int FEAT, bool COUNT, bool ALT>
+HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntS + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, true, COUNT, false>(tr,
+    walk_queue<FEAT, true, COUNT, false, ALT>(tr, exact,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int q, Ray& r, float& tMax) {
             const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
@@ -444,12 +444,12 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W
         }, C);
 }
 
-template <int FEAT, bool COUNT, bool EXISTS>
-HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
+template <int FEAT, bool COUNT, bool EXISTS, bool ALT>
+HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, const WfBuffers& W, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntA + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, false, COUNT, EXISTS>(tr,
+    walk_queue<FEAT, false, COUNT, EXISTS, ALT>(tr, exact,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int slot, Ray& r, float& tMax) {
             tMax = 1e30f;
