@@ -9,8 +9,9 @@
 // de-duplicated by case-insensitive path, a missing texture clears the material's map flag.
 // Differences, all on inputs where the reference throws or depends on the OS:
 //   * '\\' in mtllib / map paths is treated as a directory separator (the reference targets Windows, where it is);
-//   * images other than .tga go through System.Drawing in the reference; here uncompressed 24/32-bit .bmp is
-//     read natively and any other format is an error (HRTH_ERR_FORMAT) instead of a silent substitute;
+//   * images other than .tga go through System.Drawing in the reference; here .png (all colour types at up to 8 bits per sample,
+//     transparency, Adam7; own inflate) and uncompressed 24/32-bit .bmp are read natively and any other format (.jpg: a lossy
+//     decoder's output is implementation-defined, GDI+'s cannot be reproduced) is an error (HRTH_ERR_FORMAT), never a substitute;
 //   * .NET exceptions (FormatException, InvalidDataException, EndOfStreamException) become error codes + a message.
 #include <cstdint>
 #include <cstdio>
@@ -292,6 +293,253 @@ Image load_bmp(const std::string& file)
     return img;
 }
 
+// ---- PNG ------------------------------------------------------------------------------------------------
+// What `new Bitmap(file)` + LockBits(Format32bppArgb) delivers for a PNG (MeshLoaderOBJ.cs:463-511): rows top-down, B,G,R,A.
+// Decoder written from the PNG (ISO/IEC 15948) and DEFLATE / zlib (RFC 1951 / 1950) specifications: all colour types at 1-8 bits
+// per sample, palette transparency (tRNS), colour-key transparency of grey / RGB images, Adam7 interlace, CRC-32 and Adler-32
+// verified.  16 bits per sample fail loudly (how GDI+ narrows them is not something this repository can pin), ancillary colour
+// chunks (gAMA, sRGB, iCCP, cHRM) are ignored: samples are delivered as stored.  PARITY UNPINNED like the rest of the loader.
+struct Inflater {
+    const uint8_t* in; size_t n, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0; const std::string& file;
+    std::vector<uint8_t> out;
+    [[noreturn]] void bad(const char* what) { fail(std::string("PNG: ") + what + ": " + file); }
+    int bits(int need)
+    {
+        uint32_t v = bitbuf;
+        while (bitcnt < need) { if (pos >= n) bad("compressed stream ends early"); v |= (uint32_t)in[pos++] << bitcnt; bitcnt += 8; }
+        bitbuf = need == 32 ? 0 : v >> need; bitcnt -= need;
+        return (int)(v & ((need == 32 ? 0u : (1u << need)) - 1u));
+    }
+    struct Huff { short count[16]; short symbol[288]; };
+    static bool build(Huff& h, const short* length, int n)
+    {
+        for (int i = 0; i < 16; i++) h.count[i] = 0;
+        for (int i = 0; i < n; i++) h.count[length[i]]++;
+        if (h.count[0] == n) return true;                            // no codes: legal for an unused distance tree
+        int left = 1;
+        for (int len = 1; len < 16; len++) { left <<= 1; left -= h.count[len]; if (left < 0) return false; }
+        short offs[16]; offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = (short)(offs[len] + h.count[len]);
+        for (int i = 0; i < n; i++) if (length[i] != 0) h.symbol[offs[length[i]]++] = (short)i;
+        return true;
+    }
+    int decode(const Huff& h)
+    {   // canonical code, one bit at a time (RFC 1951 3.2.2)
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len < 16; len++)
+        {
+            code |= bits(1);
+            const int count = h.count[len];
+            if (code - count < first) return h.symbol[index + (code - first)];
+            index += count; first += count; first <<= 1; code <<= 1;
+        }
+        bad("invalid Huffman code");
+    }
+    void codes(const Huff& lencode, const Huff& distcode)
+    {
+        static const short lens[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const short lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const short dists[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const short dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (;;)
+        {
+            int sym = decode(lencode);
+            if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+            if (sym == 256) return;
+            sym -= 257;
+            if (sym >= 29) bad("invalid length symbol");
+            const int len = lens[sym] + bits(lext[sym]);
+            const int ds = decode(distcode);
+            if (ds >= 30) bad("invalid distance symbol");
+            const size_t dist = (size_t)dists[ds] + (size_t)bits(dext[ds]);
+            if (dist > out.size()) bad("distance reaches before the start of the output");
+            for (int k = 0; k < len; k++) out.push_back(out[out.size() - dist]);
+        }
+    }
+    void run()
+    {   // zlib wrapper (RFC 1950) around a DEFLATE stream
+        if (n < 6) bad("compressed stream too short");
+        const int cmf = in[0], flg = in[1];
+        if ((cmf & 15) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 32)) bad("not a zlib stream");
+        pos = 2;
+        int last;
+        do
+        {
+            last = bits(1);
+            const int type = bits(2);
+            if (type == 0)
+            {
+                bitbuf = 0; bitcnt = 0;
+                if (pos + 4 > n) bad("stored block header ends early");
+                const unsigned len = in[pos] | (in[pos + 1] << 8), nlen = in[pos + 2] | (in[pos + 3] << 8);
+                pos += 4;
+                if ((len ^ 0xFFFFu) != nlen || pos + len > n) bad("stored block is damaged");
+                out.insert(out.end(), in + pos, in + pos + len); pos += len;
+            }
+            else if (type == 1)
+            {
+                short l[288]; Huff lc, dc;
+                for (int i = 0; i < 144; i++) l[i] = 8;
+                for (int i = 144; i < 256; i++) l[i] = 9;
+                for (int i = 256; i < 280; i++) l[i] = 7;
+                for (int i = 280; i < 288; i++) l[i] = 8;
+                build(lc, l, 288);
+                short d[30]; for (int i = 0; i < 30; i++) d[i] = 5;
+                build(dc, d, 30);
+                codes(lc, dc);
+            }
+            else if (type == 2)
+            {
+                static const short order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                const int nlen = bits(5) + 257, ndist = bits(5) + 1, ncode = bits(4) + 4;
+                if (nlen > 286 || ndist > 30) bad("too many codes");
+                short l[320];
+                for (int i = 0; i < 19; i++) l[i] = 0;
+                for (int i = 0; i < ncode; i++) l[order[i]] = (short)bits(3);
+                Huff cl;
+                if (!build(cl, l, 19)) bad("invalid code-length code");
+                int idx = 0;
+                while (idx < nlen + ndist)
+                {
+                    int sym = decode(cl);
+                    if (sym < 16) l[idx++] = (short)sym;
+                    else
+                    {
+                        int prev = 0, rep;
+                        if (sym == 16) { if (idx == 0) bad("repeat without a previous length"); prev = l[idx - 1]; rep = 3 + bits(2); }
+                        else if (sym == 17) rep = 3 + bits(3);
+                        else rep = 11 + bits(7);
+                        if (idx + rep > nlen + ndist) bad("code lengths overrun");
+                        while (rep--) l[idx++] = (short)prev;
+                    }
+                }
+                if (l[256] == 0) bad("no end-of-block code");
+                Huff lc, dc;
+                if (!build(lc, l, nlen) || !build(dc, l + nlen, ndist)) bad("over-subscribed Huffman code");
+                codes(lc, dc);
+            }
+            else bad("invalid block type");
+        } while (!last);
+        bitbuf = 0; bitcnt = 0;
+        if (pos + 4 > n) bad("Adler-32 missing");
+        uint32_t a = 1, b = 0;
+        for (uint8_t v : out) { a = (a + v) % 65521u; b = (b + a) % 65521u; }
+        const uint32_t want = ((uint32_t)in[pos] << 24) | ((uint32_t)in[pos + 1] << 16) | ((uint32_t)in[pos + 2] << 8) | in[pos + 3];
+        if (((b << 16) | a) != want) bad("Adler-32 mismatch");
+    }
+};
+
+uint32_t crc32_png(const uint8_t* p, size_t n)
+{
+    static uint32_t table[256]; static bool ready = false;
+    if (!ready) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; } ready = true; }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 255] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+Image load_png(const std::string& file)
+{
+    const std::vector<uint8_t> bytes = read_bytes(file);
+    static const uint8_t sig[8] = {137, 80, 78, 71, 13, 10, 26, 10};
+    if (bytes.size() < 8 || std::memcmp(bytes.data(), sig, 8) != 0) fail("not a PNG file: " + file);
+    auto be32 = [&](size_t p) { return ((uint32_t)bytes[p] << 24) | ((uint32_t)bytes[p + 1] << 16) | ((uint32_t)bytes[p + 2] << 8) | bytes[p + 3]; };
+    uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    bool seenEnd = false;
+    for (size_t p = 8; !seenEnd;)
+    {
+        if (p + 12 > bytes.size()) fail("PNG: chunk list ends early: " + file);
+        const uint32_t len = be32(p);
+        if ((size_t)len > bytes.size() - p - 12) fail("PNG: chunk runs past the end of the file: " + file);
+        const std::string type((const char*)&bytes[p + 4], 4);
+        const uint8_t* data = &bytes[p + 8];
+        if (crc32_png(&bytes[p + 4], (size_t)len + 4) != be32(p + 8 + len)) fail("PNG: CRC mismatch in chunk " + type + ": " + file);
+        if (type == "IHDR")
+        {
+            if (len != 13) fail("PNG: bad IHDR: " + file);
+            w = be32(p + 8); h = be32(p + 12); depth = data[8]; ctype = data[9]; interlace = data[12];
+            if (data[10] != 0 || data[11] != 0 || interlace > 1) fail("PNG: unknown compression / filter / interlace method: " + file);
+        }
+        else if (type == "PLTE") plte.assign(data, data + len);
+        else if (type == "tRNS") trns.assign(data, data + len);
+        else if (type == "IDAT") idat.insert(idat.end(), data, data + len);
+        else if (type == "IEND") seenEnd = true;
+        else if (!(type[0] & 32)) fail("PNG: unknown critical chunk " + type + ": " + file);
+        p += (size_t)len + 12;
+    }
+    const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    const bool depthOk = depth == 8 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4));
+    if (w == 0 || h == 0 || w > 32768u || h > 32768u || channels == 0) fail("PNG: bad header: " + file);
+    if (depth == 16) fail("PNG: 16 bits per sample are not supported: " + file);
+    if (!depthOk) fail("PNG: bit depth " + std::to_string(depth) + " is not valid for colour type " + std::to_string(ctype) + ": " + file);
+    if (ctype == 3 && (plte.empty() || plte.size() % 3 != 0)) fail("PNG: palette image without a valid PLTE chunk: " + file);
+    Inflater inf{idat.data(), idat.size(), 0, 0, 0, file, {}};
+    inf.run();
+    const std::vector<uint8_t>& raw = inf.out;
+    const int bitsPerPixel = channels * depth, bpp = std::max(1, bitsPerPixel / 8);
+    Image img; img.w = (int)w; img.h = (int)h; img.bgra.assign((size_t)w * h * 4, 0);
+    auto put = [&](uint32_t x, uint32_t y, const uint8_t* line, uint32_t xi) {       // sample(s) of pixel xi of a defiltered scanline
+        uint8_t s[4] = {0, 0, 0, 255};
+        if (depth == 8) for (int c = 0; c < channels; c++) s[c] = line[(size_t)xi * channels + c];
+        else { const int per = 8 / depth; const uint8_t b = line[xi / per]; s[0] = (uint8_t)((b >> ((per - 1 - (int)(xi % per)) * depth)) & ((1 << depth) - 1)); }
+        uint8_t* o = &img.bgra[((size_t)y * w + x) * 4];
+        if (ctype == 3)
+        {
+            if ((size_t)s[0] * 3 + 2 >= plte.size()) fail("PNG: palette index out of range: " + file);
+            o[2] = plte[s[0] * 3]; o[1] = plte[s[0] * 3 + 1]; o[0] = plte[s[0] * 3 + 2];
+            o[3] = s[0] < trns.size() ? trns[s[0]] : 255;
+        }
+        else if (ctype == 0 || ctype == 4)
+        {
+            const int maxv = (1 << depth) - 1;
+            const uint8_t g = (uint8_t)(depth == 8 ? s[0] : s[0] * 255 / maxv);                // 1 / 2 / 4-bit greys scale to 0..255
+            o[0] = o[1] = o[2] = g;
+            o[3] = ctype == 4 ? s[1] : ((trns.size() >= 2 && (((unsigned)trns[0] << 8) | trns[1]) == (unsigned)s[0]) ? 0 : 255);
+        }
+        else
+        {
+            o[2] = s[0]; o[1] = s[1]; o[0] = s[2];
+            if (ctype == 6) o[3] = s[3];
+            else o[3] = (trns.size() >= 6 && trns[1] == s[0] && trns[3] == s[1] && trns[5] == s[2] && trns[0] == 0 && trns[2] == 0 && trns[4] == 0) ? 0 : 255;
+        }
+    };
+    size_t at = 0;
+    std::vector<uint8_t> prev, cur;
+    auto pass = [&](uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) {
+        if (x0 >= w || y0 >= h) return;
+        const uint32_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+        const size_t stride = ((size_t)pw * bitsPerPixel + 7) / 8;
+        prev.assign(stride, 0); cur.resize(stride);
+        for (uint32_t r = 0; r < ph; r++)
+        {
+            if (at + 1 + stride > raw.size()) fail("PNG: image data ends early: " + file);
+            const int ft = raw[at++];
+            if (ft > 4) fail("PNG: unknown filter type: " + file);
+            for (size_t i = 0; i < stride; i++)
+            {
+                const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                if (ft == 1) pred = a;
+                else if (ft == 2) pred = b;
+                else if (ft == 3) pred = (a + b) >> 1;
+                else if (ft == 4) { const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+                cur[i] = (uint8_t)(raw[at + i] + pred);
+            }
+            at += stride;
+            for (uint32_t xi = 0; xi < pw; xi++) put(x0 + xi * dx, y0 + r * dy, cur.data(), xi);
+            prev.swap(cur);
+        }
+    };
+    if (interlace == 0) pass(0, 0, 1, 1);
+    else
+    {
+        static const uint32_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int k = 0; k < 7; k++) pass(px0[k], py0[k], pdx[k], pdy[k]);
+    }
+    return img;
+}
+
 Image load_texture(const std::string& file)                         // LoadTextureBGRA :456-479
 {
     size_t dot = file.find_last_of('.');
@@ -299,7 +547,8 @@ Image load_texture(const std::string& file)                         // LoadTextu
     std::string ext = (dot != std::string::npos && (slash == std::string::npos || dot > slash)) ? lower_ascii(file.substr(dot)) : std::string();
     if (ext == ".tga") return load_tga(file);
     if (ext == ".bmp") return load_bmp(file);
-    fail("image format '" + ext + "' is not supported (only .tga and uncompressed .bmp): " + file);
+    if (ext == ".png") return load_png(file);
+    fail("image format '" + ext + "' is not supported (only .tga, .png at up to 8 bits per sample and uncompressed .bmp): " + file);
 }
 
 // ---- OBJ / MTL ------------------------------------------------------------------------------------------

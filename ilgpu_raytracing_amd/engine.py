@@ -221,7 +221,7 @@ def load_obj(path, scale=1.0, flip_winding=True):
 
 
 def load_image(path):
-    """LoadTextureBGRA (MeshLoaderOBJ.cs:456-593): .tga (raw / RLE, 8/24/32 bit) or uncompressed .bmp -> (H, W, 4) uint8 BGRA, row 0 = top."""
+    """LoadTextureBGRA (MeshLoaderOBJ.cs:456-593): .tga (raw / RLE, 8/24/32 bit), .png (<= 8 bits per sample) or uncompressed .bmp -> (H, W, 4) uint8 BGRA, row 0 = top."""
     w, h, p = C.c_int(), C.c_int(), C.POINTER(C.c_uint8)()
     rc = lib().hrth_image_load(os.fsencode(path), C.byref(w), C.byref(h), C.byref(p))
     if rc != 0:

@@ -16,7 +16,7 @@
  *                                                                     Scene.cs:151-256
  *   hrth_mesh_load_obj / _get / _free  MeshLoaderOBJ.Load -> MeshHost (OBJ + MTL + textures)
  *                                                                     MeshLoaderOBJ.cs:67-277,339-443
- *   hrth_image_load / _free            LoadTextureBGRA (TGA raw/RLE; BMP) MeshLoaderOBJ.cs:456-593
+ *   hrth_image_load / _free            LoadTextureBGRA (TGA raw/RLE; PNG <= 8 bits per sample; BMP) MeshLoaderOBJ.cs:456-593
  *   hrth_scene_load_obj_instance       Scene.LoadObjInstance(objPath, objectToWorld, uniformScale)
  *                                                                     Scene.cs:144-256
  *   hrth_scene_rebuild_tlas            Scene.RebuildTLAS              Scene.cs:358-368

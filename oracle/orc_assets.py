@@ -239,6 +239,114 @@ def _load_mtl(path, base):
     return mats, dpaths, apaths
 
 
+def load_png(path):
+    """PNG -> (H, W, 4) uint8 BGRA, row 0 = top: what `new Bitmap(file)` + LockBits(Format32bppArgb) hands the reference loader
+    (MeshLoaderOBJ.cs:463-511).  Independent of the product's decoder: chunk walk with struct, zlib.decompress for the IDAT
+    stream, numpy-free defiltering.  Colour types 0 / 2 / 3 / 4 / 6 at <= 8 bits per sample, tRNS, Adam7."""
+    import zlib
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:8] != b"\x89PNG\r\n\x1a\n":
+        raise FormatError("not a PNG")
+    pos, idat, plte, trns, hdr = 8, b"", b"", b"", None
+    while True:
+        if pos + 12 > len(d):
+            raise FormatError("PNG chunk list ends early")
+        n, typ = struct.unpack(">I4s", d[pos:pos + 8])
+        if n > len(d) - pos - 12:
+            raise FormatError("PNG chunk runs past the end")
+        body = d[pos + 8:pos + 8 + n]
+        if zlib.crc32(d[pos + 4:pos + 8 + n]) & 0xFFFFFFFF != struct.unpack(">I", d[pos + 8 + n:pos + 12 + n])[0]:
+            raise FormatError("PNG CRC")
+        pos += 12 + n
+        if typ == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"PLTE":
+            plte = body
+        elif typ == b"tRNS":
+            trns = body
+        elif typ == b"IDAT":
+            idat += body
+        elif typ == b"IEND":
+            break
+        elif not (typ[0] & 32):
+            raise FormatError("unknown critical PNG chunk")
+    w, h, depth, ctype, comp, flt, lace = hdr
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}.get(ctype, 0)
+    if channels == 0 or comp or flt or lace > 1 or w == 0 or h == 0:
+        raise FormatError("PNG header")
+    if depth == 16 or not (depth == 8 or (ctype in (0, 3) and depth in (1, 2, 4))):
+        raise FormatError("PNG bit depth")
+    raw = zlib.decompress(idat)
+    bits = channels * depth
+    bpp = max(1, bits // 8)
+    out = np.zeros((h, w, 4), np.uint8)
+
+    def pixel(line, xi):
+        if depth == 8:
+            s = list(line[xi * channels:xi * channels + channels])
+        else:
+            per = 8 // depth
+            s = [(line[xi // per] >> ((per - 1 - xi % per) * depth)) & ((1 << depth) - 1)]
+        if ctype == 3:
+            if s[0] * 3 + 2 >= len(plte):
+                raise FormatError("PNG palette index")
+            r, g, b = plte[s[0] * 3:s[0] * 3 + 3]
+            return (b, g, r, trns[s[0]] if s[0] < len(trns) else 255)
+        if ctype in (0, 4):
+            g = s[0] if depth == 8 else s[0] * 255 // ((1 << depth) - 1)
+            if ctype == 4:
+                a = s[1]
+            else:
+                a = 0 if (len(trns) >= 2 and struct.unpack(">H", trns[:2])[0] == s[0]) else 255
+            return (g, g, g, a)
+        a = s[3] if ctype == 6 else (0 if (len(trns) >= 6 and struct.unpack(">HHH", trns[:6]) == tuple(s[:3])) else 255)
+        return (s[2], s[1], s[0], a)
+
+    at = 0
+    passes = [(0, 0, 1, 1)] if lace == 0 else [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    for x0, y0, dx, dy in passes:
+        if x0 >= w or y0 >= h:
+            continue
+        pw, ph = (w - x0 + dx - 1) // dx, (h - y0 + dy - 1) // dy
+        stride = (pw * bits + 7) // 8
+        prev = bytearray(stride)
+        for r in range(ph):
+            if at + 1 + stride > len(raw):
+                raise FormatError("PNG data ends early")
+            ft = raw[at]
+            src = raw[at + 1:at + 1 + stride]
+            at += 1 + stride
+            cur = bytearray(stride)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 0:
+                    pr = 0
+                elif ft == 1:
+                    pr = a
+                elif ft == 2:
+                    pr = b
+                elif ft == 3:
+                    pr = (a + b) // 2
+                elif ft == 4:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise FormatError("PNG filter")
+                cur[i] = (src[i] + pr) & 255
+            for xi in range(pw):
+                out[y0 + r * dy, x0 + xi * dx] = pixel(cur, xi)
+            prev = cur
+    return out
+
+
+def load_image(path):
+    return load_png(path) if path.lower().endswith(".png") else load_tga(path)
+
+
 def load_tga(path):
     with open(path, "rb") as f:
         d = f.read()
@@ -373,10 +481,10 @@ def load_obj(path, scale=1.0, flip_winding=True):
                     else:
                         m["HasDiffuseMap"] = 0; m["DiffuseTexIndex"] = -1
                     continue
-                if not p.lower().endswith(".tga"):
-                    raise FormatError("oracle reads TGA only")
+                if not p.lower().endswith((".tga", ".png")):
+                    raise FormatError("oracle reads TGA and PNG only")
                 path_to_idx[key] = len(textures)
-                textures.append(load_tga(p)); tex_paths.append(p)
+                textures.append(load_image(p)); tex_paths.append(p)
             ti = path_to_idx[key]
             if alpha:
                 m["HasAlphaMap"] = 1; m["AlphaTexIndex"] = ti; m["TwoSided"] = 1

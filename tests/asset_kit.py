@@ -61,6 +61,83 @@ def write_bmp(path, bgra, bits=24, bottom_up=True, alpha_mask=False):
         f.write(b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + info + bytes(body))
 
 
+def write_png(path, samples, ctype, depth=8, interlace=False, palette=None, trns=None, filters=None, idat_split=3, level=6, seed=1):
+    """Writes a PNG from raw samples: `samples` = (H, W, channels) integers in [0, 2^depth) (channels: 1 for colour types 0 / 3,
+    2 for 4, 3 for 2, 4 for 6).  Scanline filters are chosen per row (random unless `filters` gives the sequence), the IDAT stream
+    is cut into `idat_split` chunks, Adam7 interlace on request.  Independent of both decoders under test (zlib for DEFLATE)."""
+    import zlib
+    rng = np.random.RandomState(seed)
+    h, w, ch = samples.shape
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def pack(rows):      # (ph, pw, ch) -> list of scanline byte strings
+        out = []
+        for r in rows:
+            if depth == 8:
+                out.append(bytes(int(v) for v in r.reshape(-1)))
+            else:
+                per = 8 // depth
+                vals = [int(v) for v in r.reshape(-1)]
+                line = bytearray((len(vals) * depth + 7) // 8)
+                for i, v in enumerate(vals):
+                    line[i // per] |= v << ((per - 1 - i % per) * depth)
+                out.append(bytes(line))
+        return out
+
+    def filt(lines):
+        res = bytearray()
+        prev = bytes(len(lines[0])) if lines else b""
+        for k, cur in enumerate(lines):
+            ft = (filters[k % len(filters)] if filters else int(rng.randint(0, 5)))
+            enc = bytearray(len(cur))
+            for i in range(len(cur)):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 0:
+                    pr = 0
+                elif ft == 1:
+                    pr = a
+                elif ft == 2:
+                    pr = b
+                elif ft == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                enc[i] = (cur[i] - pr) & 255
+            res.append(ft); res += enc
+            prev = cur
+        return bytes(res)
+
+    raw = b""
+    passes = [(0, 0, 1, 1)] if not interlace else [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    for x0, y0, dx, dy in passes:
+        sub = samples[y0::dy, x0::dx]
+        if sub.shape[0] and sub.shape[1]:
+            raw += filt(pack(sub))
+    z = zlib.compress(raw, level)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    out += chunk(b"gAMA", struct.pack(">I", 45455))                     # ancillary, must be ignored
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(int(v) for v in np.asarray(palette).reshape(-1)))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    n = max(1, idat_split)
+    step = (len(z) + n - 1) // n
+    for i in range(0, len(z), max(1, step)):
+        out += chunk(b"IDAT", z[i:i + step])
+    out += chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(out)
+
+
 def checker(w, h, cell, c0, c1, alpha=255):
     yy, xx = np.mgrid[0:h, 0:w]
     k = ((xx // cell + yy // cell) & 1).astype(np.uint8)[..., None]

@@ -380,6 +380,76 @@ def test_bmp_reader(tmp_path, bits, bottom_up, alpha):
     assert np.array_equal(got, want)
 
 
+PNG_CASES = {
+    # name: (ctype, depth, channels, interlace, level)
+    "rgb8": (2, 8, 3, False, 6), "rgba8": (6, 8, 4, False, 9), "grey8": (0, 8, 1, False, 6), "grey_alpha8": (4, 8, 2, False, 1),
+    "palette8": (3, 8, 1, False, 6), "palette4": (3, 4, 1, False, 6), "palette1": (3, 1, 1, False, 6), "grey2": (0, 2, 1, False, 6),
+    "rgb8_adam7": (2, 8, 3, True, 6), "rgba8_adam7": (6, 8, 4, True, 6), "palette4_adam7": (3, 4, 1, True, 6), "rgb8_stored": (2, 8, 3, False, 0),
+}
+
+
+@pytest.mark.parametrize("name", list(PNG_CASES))
+def test_png_reader(tmp_path, name):
+    """The product's PNG decoder (own inflate, defilter, Adam7; csrc/hrt_assets.cpp) against an independent restatement
+    (oracle/orc_assets.py: zlib + its own defilter) and against the samples the test wrote: every colour type, sub-byte depths,
+    all five scanline filters, palette / colour-key transparency, several IDAT chunks, stored / fixed / dynamic DEFLATE blocks."""
+    ctype, depth, ch, lace, level = PNG_CASES[name]
+    rng = np.random.RandomState(len(name) * 7 + depth)
+    w, h = (23, 17) if not lace else (19, 13)
+    smp = rng.randint(0, 1 << depth, (h, w, ch))
+    if level == 9:                                   # long matches: a smooth image compresses into back-references
+        smp = (np.add.outer(np.arange(h), np.arange(w))[..., None] // 3 + np.arange(ch)) % 256
+    pal = trns = None
+    if ctype == 3:
+        pal = rng.randint(0, 256, (1 << depth, 3))
+        trns = list(rng.randint(0, 256, (1 << depth) // 2))
+    elif ctype == 0:
+        trns = [0, int(smp[0, 0, 0])]
+    elif ctype == 2:
+        trns = [0, int(smp[1, 2, 0]), 0, int(smp[1, 2, 1]), 0, int(smp[1, 2, 2])]
+    p = str(tmp_path / (name + ".png"))
+    K.write_png(p, smp, ctype, depth, lace, pal, trns, level=level, seed=depth + ch)
+    got = engine.load_image(p)
+    ref = OA.load_png(p)
+    assert got.shape == (h, w, 4) and np.array_equal(got, ref)
+    # and against the written samples directly
+    if ctype == 6:
+        want = smp[..., [2, 1, 0, 3]]
+    elif ctype == 2:
+        a = np.where((smp == smp[1, 2]).all(-1), 0, 255)
+        want = np.concatenate([smp[..., [2, 1, 0]], a[..., None]], -1)
+    elif ctype == 4:
+        want = smp[..., [0, 0, 0, 1]]
+    elif ctype == 0:
+        g = smp[..., 0] * 255 // ((1 << depth) - 1)
+        want = np.stack([g, g, g, np.where(smp[..., 0] == smp[0, 0, 0], 0, 255)], -1)
+    else:
+        idx = smp[..., 0]
+        a = np.array([trns[i] if i < len(trns) else 255 for i in range(1 << depth)])
+        want = np.concatenate([pal[idx][..., ::-1], a[idx][..., None]], -1)
+    assert np.array_equal(got, want.astype(np.uint8))
+
+
+def test_png_errors_are_loud(tmp_path):
+    import struct, zlib
+    good = str(tmp_path / "g.png")
+    K.write_png(good, np.zeros((4, 4, 3), int), 2)
+    data = open(good, "rb").read()
+    cases = {"crc": data[:40] + bytes([data[40] ^ 1]) + data[41:], "trunc": data[:-20], "sig": b"\x89PNX" + data[4:]}
+    deep = str(tmp_path / "deep.png")
+    K.write_png(deep, np.zeros((2, 2, 3), int), 2)
+    d16 = bytearray(open(deep, "rb").read()); d16[24] = 16
+    d16[29:33] = struct.pack(">I", zlib.crc32(bytes(d16[12:29])) & 0xFFFFFFFF)
+    cases["16bit"] = bytes(d16)
+    for k, blob in cases.items():
+        p = str(tmp_path / (k + ".png"))
+        open(p, "wb").write(blob)
+        with pytest.raises((engine.AssetFormatError, OSError, ValueError)):
+            engine.load_image(p)
+        with pytest.raises(Exception):
+            OA.load_png(p)
+
+
 # ------------------------------------------------------------------------------------- whole asset -> scene arrays
 def _orc_mesh(ref):
     mats = []
