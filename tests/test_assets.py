@@ -303,13 +303,27 @@ def test_texture_binding_dedupe_missing_and_backslashes(tmp_path):
 
 
 def test_unsupported_image_format_fails_loudly(tmp_path):
+    obj, mtl = _tri_obj(["newmtl a", "map_Kd pic.jpg"])
+    write(tmp_path / "m.obj", obj)
+    write(tmp_path / "m.mtl", mtl)
+    with open(tmp_path / "pic.jpg", "wb") as f:
+        f.write(b"\xff\xd8\xff\xe0")
+    with pytest.raises(engine.AssetFormatError, match="not supported"):
+        engine.load_obj(str(tmp_path / "m.obj"))
+
+
+def test_png_texture_through_the_obj_loader(tmp_path):
+    """map_Kd naming a .png: the texture reaches the mesh exactly as the image reader delivers it, and as the oracle's loader does."""
     obj, mtl = _tri_obj(["newmtl a", "map_Kd pic.png"])
     write(tmp_path / "m.obj", obj)
     write(tmp_path / "m.mtl", mtl)
-    with open(tmp_path / "pic.png", "wb") as f:
-        f.write(b"\x89PNG\r\n\x1a\n")
-    with pytest.raises(engine.AssetFormatError, match="not supported"):
-        engine.load_obj(str(tmp_path / "m.obj"))
+    rng = np.random.RandomState(4)
+    K.write_png(str(tmp_path / "pic.png"), rng.randint(0, 256, (6, 5, 4)), 6)
+    got = engine.load_obj(str(tmp_path / "m.obj"))
+    ref = OA.load_obj(str(tmp_path / "m.obj"))
+    img = engine.load_image(str(tmp_path / "pic.png"))
+    assert got.n_tex == 1 and (int(got.tex_w[0]), int(got.tex_h[0])) == (5, 6)
+    assert np.array_equal(got.tex_bytes.reshape(6, 5, 4), ref["textures"][0]) and np.array_equal(got.tex_bytes.reshape(6, 5, 4), img)
 
 
 # ------------------------------------------------------------------------------------- TGA / BMP
