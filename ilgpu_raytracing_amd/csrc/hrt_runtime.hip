@@ -314,7 +314,6 @@ struct DeviceState {
     int n_cu = 256;                            // compute units (MI355X: 256)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;             // shadow walks run beside the closest-hit walks of the same bounce
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
     static constexpr int kRing = 128;          // frames that may be in flight between two syncs
     hipEvent_t ev[kRing][4] = {};
     int ring_head = 0;                         // frames enqueued since the last synchronize
@@ -343,8 +342,13 @@ struct DeviceState {
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
     // streamed path-trace workspace
-    float* wf_mem = nullptr; size_t wf_bytes = 0;
-    int* wf_cnt = nullptr; size_t wf_cnt_ints = 0;
+    // two sample batches are in flight at a time (lane 0 on stream / stream2, lane 1 on stream3 / stream4): each has its own workspace
+    float* wf_mem[2] = {}; size_t wf_bytes[2] = {};
+    int* wf_cnt[2] = {}; size_t wf_cnt_ints[2] = {};
+    float* wf_accum = nullptr; size_t wf_accum_floats = 0;     // Lframe carried across the batches of a frame (one plane set, shared)
+    hipStream_t stream3 = nullptr, stream4 = nullptr;
+    hipEvent_t evLane[2][3] = {};              // per lane: fork, join, resolve done
+    hipEvent_t evStage = nullptr;
     int* wf_ovf = nullptr;                     // wide walker stack overflow area (allocated on first use)
     float* split_mem = nullptr; size_t split_floats = 0;    // fused kernel in sample groups: per-sample radiance + staged reservoirs
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
@@ -488,13 +492,18 @@ void free_present(DeviceState& d)
 
 void free_workspace(DeviceState& d)
 {
-    if (d.wf_mem) (void)hipFree(d.wf_mem);
-    if (d.wf_cnt) (void)hipFree(d.wf_cnt);
+    for (int j = 0; j < 2; j++)
+    {
+        if (d.wf_mem[j]) (void)hipFree(d.wf_mem[j]);
+        if (d.wf_cnt[j]) (void)hipFree(d.wf_cnt[j]);
+        d.wf_mem[j] = nullptr; d.wf_cnt[j] = nullptr; d.wf_bytes[j] = 0; d.wf_cnt_ints[j] = 0;
+    }
+    if (d.wf_accum) (void)hipFree(d.wf_accum);
+    d.wf_accum = nullptr; d.wf_accum_floats = 0;
     if (d.wf_ovf) (void)hipFree(d.wf_ovf);
     d.wf_ovf = nullptr;
     if (d.split_mem) (void)hipFree(d.split_mem);
     d.split_mem = nullptr; d.split_floats = 0;
-    d.wf_mem = nullptr; d.wf_cnt = nullptr; d.wf_bytes = 0; d.wf_cnt_ints = 0;
 }
 
 void free_scene(DeviceState& d)
@@ -1017,31 +1026,40 @@ int gather_rows(hrt_ctx* c, DeviceState& d, T* host, const T* devp, int width)
 constexpr long long kSmallSceneNodes = 256;
 constexpr long long kWfMaxPaths = 1ll << 25;      // paths resident per sample batch (320 B of workspace each)
 
-int ensure_workspace(hrt_ctx* c, DeviceState& d, long long cap, int nOrd, int nRanges, int maxDepth, WfBuffers& W)
+// workspace of batch lane `lane` (0 / 1); growing one drains the device first (frames of earlier calls may still use it)
+int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nOrd, int nRanges, int maxDepth, WfBuffers& W)
 {
     const size_t planes = 2 * V_PLANES + R_PLANES + S_PLANES + 3 + G_PLANES;
-    const size_t bytes = ((size_t)planes * (size_t)cap + 3 * (size_t)nOrd) * sizeof(float);
+    const size_t bytes = (size_t)planes * (size_t)cap * sizeof(float);
     const size_t ints = (size_t)(2 * maxDepth + 2) * (size_t)nRanges + (size_t)maxDepth * 16;
-    if (bytes > d.wf_bytes)
+    if (bytes > d.wf_bytes[lane])
     {
-        if (d.wf_mem) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.wf_mem); d.wf_mem = nullptr; d.wf_bytes = 0; }
+        if (d.wf_mem[lane]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(d.wf_mem[lane]); d.wf_mem[lane] = nullptr; d.wf_bytes[lane] = 0; }
         void* v = nullptr;
         HIPCHK(c, hipMalloc(&v, bytes));
-        d.wf_mem = (float*)v; d.wf_bytes = bytes;
+        d.wf_mem[lane] = (float*)v; d.wf_bytes[lane] = bytes;
     }
-    if (ints > d.wf_cnt_ints)
+    if (ints > d.wf_cnt_ints[lane])
     {
-        if (d.wf_cnt) { HIPCHK(c, hipStreamSynchronize(d.stream)); (void)hipFree(d.wf_cnt); d.wf_cnt = nullptr; d.wf_cnt_ints = 0; }
+        if (d.wf_cnt[lane]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(d.wf_cnt[lane]); d.wf_cnt[lane] = nullptr; d.wf_cnt_ints[lane] = 0; }
         void* v = nullptr;
         HIPCHK(c, hipMalloc(&v, ints * sizeof(int)));
-        d.wf_cnt = (int*)v; d.wf_cnt_ints = ints;
+        d.wf_cnt[lane] = (int*)v; d.wf_cnt_ints[lane] = ints;
     }
-    float* m = d.wf_mem;
+    if ((size_t)3 * (size_t)nOrd > d.wf_accum_floats)
+    {
+        if (d.wf_accum) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(d.wf_accum); d.wf_accum = nullptr; d.wf_accum_floats = 0; }
+        void* v = nullptr;
+        HIPCHK(c, hipMalloc(&v, (size_t)3 * (size_t)nOrd * sizeof(float)));
+        d.wf_accum = (float*)v; d.wf_accum_floats = (size_t)3 * (size_t)nOrd;
+    }
+    float* m = d.wf_mem[lane];
     auto take = [&](int nplanes, long long stride) { Planes pl; pl.base = m; pl.stride = stride; m += (size_t)nplanes * (size_t)stride; return pl; };
     W.A = take(V_PLANES, cap); W.B = take(V_PLANES, cap); W.R = take(R_PLANES, cap); W.SQ = take(S_PLANES, cap);
-    W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap); W.accum = take(3, nOrd);
-    W.cntA = d.wf_cnt; W.cntS = d.wf_cnt + (size_t)(maxDepth + 1) * (size_t)nRanges;
-    W.grab = d.wf_cnt + (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
+    W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap);
+    W.accum.base = d.wf_accum; W.accum.stride = nOrd;
+    W.cntA = d.wf_cnt[lane]; W.cntS = d.wf_cnt[lane] + (size_t)(maxDepth + 1) * (size_t)nRanges;
+    W.grab = d.wf_cnt[lane] + (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
     W.ovf = d.wf_ovf;
     W.nRanges = nRanges;
     return HRT_OK;
@@ -1104,12 +1122,32 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     long long sb = maxPaths / g.nOrd;
     if (sb < 1) sb = 1;
     if (sb > spp) sb = spp;
+    // Two sample batches in flight: the walks of one are latency-bound and leave the vector units idle most of the time, the
+    // shade / finish / resolve kernels of the other fill them (measured first as two processes sharing the card: configs 4 / 5
+    // -11 % / -7 %).  A frame that fits one batch is cut into two halves; only the ordered steps -- the per-pixel sample sum
+    // and the last-writer reservoir in wf_resolve -- are chained by events, in batch order.
+#ifdef HRT_ONE_BATCH_LANE          // A/B
+    const int nLanes = 1;
+#else
+    // ... a frame that fits one batch is cut in two only while each half still fills the machine (measured: halves of 16.6 M paths
+    // config 3 -5.5 %, config 4 +-0; halves of 8.3 M paths config 5 +13 %)
+    constexpr long long kMinHalfBatchPaths = 1ll << 24;
+    const bool severalBatches = sb < spp;
+    const bool halves = !severalBatches && spp >= 2 && (long long)((spp + 1) / 2) * g.nOrd >= kMinHalfBatchPaths;
+    const int nLanes = (severalBatches || halves) ? 2 : 1;
+#endif
+    if (nLanes == 2 && sb > (spp + 1) / 2) sb = (spp + 1) / 2;
     const long long batchPaths = sb * (long long)g.nOrd;
     const int nRanges = (int)((batchPaths + kRange - 1) / kRange);
     const long long cap = (long long)nRanges * kRange;
-    WfBuffers W;
-    int rc = ensure_workspace(c, d, cap, g.nOrd, nRanges, k.maxDepth, W);
-    if (rc != HRT_OK) return rc;
+    WfBuffers Wl[2];
+    for (int j = 0; j < nLanes; j++) { int rc = ensure_workspace(c, d, j, cap, g.nOrd, nRanges, k.maxDepth, Wl[j]); if (rc != HRT_OK) return rc; }
+    hipStream_t laneMain[2] = {d.stream, d.stream3}, laneSide[2] = {d.stream2, d.stream4};
+    if (nLanes == 2)
+    {   // lane 1 starts behind everything enqueued so far (this frame's primary launch, the previous frame)
+        HIPCHK(c, hipEventRecord(d.evStage, d.stream));
+        HIPCHK(c, hipStreamWaitEvent(d.stream3, d.evStage, 0));
+    }
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
     // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
@@ -1124,15 +1162,19 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     {
         void* v = nullptr;
         HIPCHK(c, hipMalloc(&v, (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));
-        d.wf_ovf = (int*)v; W.ovf = d.wf_ovf;
+        d.wf_ovf = (int*)v; Wl[0].ovf = d.wf_ovf; Wl[1].ovf = d.wf_ovf;
     }
 #else
     constexpr bool wide = false;
     (void)wideEnv;
 #endif
-    for (int b0 = 0; b0 < spp; b0 += (int)sb)
+    int batch = 0;
+    for (int b0 = 0; b0 < spp; b0 += (int)sb, batch++)
     {
-        if (k.maxDepth > 0) HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), d.stream));
+        const int lane = batch % nLanes;
+        const WfBuffers& W = Wl[lane];
+        const hipStream_t sMain = laneMain[lane], sSide = laneSide[lane];
+        if (k.maxDepth > 0) HIPCHK(c, hipMemsetAsync(W.grab, 0, (size_t)k.maxDepth * 16 * sizeof(int), sMain));
         g.batchStart = b0;
         g.batchCount = (int)std::min<long long>(sb, spp - b0);
         g.lastBatch = (b0 + g.batchCount >= spp) ? 1 : 0;
@@ -1147,11 +1189,11 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
             const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0 || wide) ? 1 : 0;      // the wide walker's overflow area is sized for the persistent grid
             if (depth == 0)
             {
-                if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
-                else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false, true>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, true>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false, true>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             }
-            else if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
-            else            hipLaunchKernelGGL((hrt_wf_shade_kernel<false, false>), gridR, block, 0, d.stream, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            else if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, false>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+            else            hipLaunchKernelGGL((hrt_wf_shade_kernel<false, false>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             if constexpr (PackedFeat<TR>::value >= 0)
             {   // packed layout: persistent-wave walks + finish
                 constexpr int F = PackedFeat<TR>::value;
@@ -1180,54 +1222,59 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 };
                 if (count)
                 {
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, tr, W, vsel, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, d.stream, tr, tr, W, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, sMain, tr, tr, W, vsel, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, sMain, tr, tr, W, depth, chained, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
                 }
 #ifdef HRT_TUNING
                 else if (wide)
                 {
-                    hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, vsel, depth, chained);
-                    hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, d.stream, tr, W, depth, chained);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                    hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, sMain, tr, W, vsel, depth, chained);
+                    hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, sMain, tr, W, depth, chained);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
                 }
 #endif
                 else if ((chained || forkStatic) && forkShadow)
                 {   // the two walks of a bounce are independent (shadow requests vs bounce rays) and both are persistent
                     // launches that end in a drain: on two streams the second one's workgroups move into the wave slots
                     // the first one's drain frees, instead of waiting for its last ray
-                    HIPCHK(c, hipEventRecord(d.evFork, d.stream));
-                    HIPCHK(c, hipStreamWaitEvent(d.stream2, d.evFork, 0));
-                    launch_closest(d.stream);
-                    launch_shadow(d.stream2);
-                    HIPCHK(c, hipEventRecord(d.evJoin, d.stream2));
-                    HIPCHK(c, hipStreamWaitEvent(d.stream, d.evJoin, 0));
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                    HIPCHK(c, hipEventRecord(d.evLane[lane][0], sMain));
+                    HIPCHK(c, hipStreamWaitEvent(sSide, d.evLane[lane][0], 0));
+                    launch_closest(sMain);
+                    launch_shadow(sSide);
+                    HIPCHK(c, hipEventRecord(d.evLane[lane][1], sSide));
+                    HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[lane][1], 0));
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
                 }
                 else
                 {
-                    launch_shadow(d.stream);
-                    launch_closest(d.stream);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth);
+                    launch_shadow(sMain);
+                    launch_closest(sMain);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
                 }
             }
             else
             {   // reference layout: one-ray-per-lane walks
                 if (count)
                 {
-                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, true>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, true>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, true>), gridR, block, 0, sMain, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, true>), gridR, block, 0, sMain, tr, k, W, vsel, depth, cnt1);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, false>), gridR, block, 0, d.stream, tr, W, vsel, depth, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, false>), gridR, block, 0, d.stream, tr, k, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_shadow_kernel<TR, false>), gridR, block, 0, sMain, tr, W, vsel, depth, cnt1);
+                    hipLaunchKernelGGL((hrt_wf_closest_kernel<TR, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth, cnt1);
                 }
             }
         }
-        hipLaunchKernelGGL(hrt_wf_resolve_kernel, gridP, block, 0, d.stream, k, g, d.gb, d.fb, resCur, W);
+        // ordered part: Lframe is summed in sample order and resCur keeps its last writer, so a batch resolves after its predecessor
+        if (batch > 0 && nLanes == 2) HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[1 - lane][2], 0));
+        hipLaunchKernelGGL(hrt_wf_resolve_kernel, gridP, block, 0, sMain, k, g, d.gb, d.fb, resCur, W);
         HIPCHK(c, hipGetLastError());
+        if (nLanes == 2) HIPCHK(c, hipEventRecord(d.evLane[lane][2], sMain));
     }
+    // the frame ends on the device's main stream: the resolves form one chain, so its last link covers every batch of both lanes
+    if (nLanes == 2 && batch > 1) HIPCHK(c, hipStreamWaitEvent(d.stream, d.evLane[1][2], 0));
     return HRT_OK;
 }
 
@@ -1279,8 +1326,11 @@ try {
         if (err == hipSuccess) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d.device_id) == hipSuccess && cu > 0) d.n_cu = cu; }
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evFork, hipEventDisableTiming);
-        if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evJoin, hipEventDisableTiming);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream3, hipStreamNonBlocking);
+        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream4, hipStreamNonBlocking);
+        for (int j = 0; j < 2 && err == hipSuccess; j++)
+            for (int e = 0; e < 3 && err == hipSuccess; e++) err = hipEventCreateWithFlags(&d.evLane[j][e], hipEventDisableTiming);
+        if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evStage, hipEventDisableTiming);
         for (int f = 0; f < DeviceState::kRing && err == hipSuccess; f++)
             for (int k = 0; k < 4 && err == hipSuccess; k++) err = hipEventCreate(&d.ev[f][k]);
         if (err == hipSuccess) { void* p = nullptr; err = hipMalloc(&p, 20 * sizeof(unsigned long long)); d.counters = (unsigned long long*)p; }
@@ -1322,9 +1372,9 @@ void hrt_destroy(hrt_ctx* c)
         if (d.counters) (void)hipFree(d.counters);
         for (int f = 0; f < DeviceState::kRing; f++)
             for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
-        if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
-        if (d.evFork) (void)hipEventDestroy(d.evFork);
-        if (d.evJoin) (void)hipEventDestroy(d.evJoin);
+        for (hipStream_t st : {d.stream2, d.stream3, d.stream4}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (int j = 0; j < 2; j++) for (int e = 0; e < 3; e++) if (d.evLane[j][e]) (void)hipEventDestroy(d.evLane[j][e]);
+        if (d.evStage) (void)hipEventDestroy(d.evStage);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
     delete c;
