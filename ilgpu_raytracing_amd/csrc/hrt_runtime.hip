@@ -309,6 +309,12 @@ namespace {
 
 thread_local std::string g_create_error;
 
+#ifndef HRT_BATCH_LANES
+#define HRT_BATCH_LANES 2
+#endif
+constexpr int kMaxLanes = 4, kBatchLanes = HRT_BATCH_LANES;      // sample batches in flight: 1 / 2 / 3 / 4 measured on configs 4 / 5 at 64 / 256 spp: 362 / 328 / 334 / 325 ms and 1412 / 1323 / 1376 / 1330 ms
+static_assert(kBatchLanes >= 1 && kBatchLanes <= kMaxLanes, "");
+
 struct DeviceState {
     int device_id = -1;
     int n_cu = 256;                            // compute units (MI355X: 256)
@@ -343,11 +349,11 @@ struct DeviceState {
     int present_w = 0, present_h = 0; bool taa_history_valid = false;
     // streamed path-trace workspace
     // two sample batches are in flight at a time (lane 0 on stream / stream2, lane 1 on stream3 / stream4): each has its own workspace
-    float* wf_mem[2] = {}; size_t wf_bytes[2] = {};
-    int* wf_cnt[2] = {}; size_t wf_cnt_ints[2] = {};
+    float* wf_mem[kMaxLanes] = {}; size_t wf_bytes[kMaxLanes] = {};
+    int* wf_cnt[kMaxLanes] = {}; size_t wf_cnt_ints[kMaxLanes] = {};
     float* wf_accum = nullptr; size_t wf_accum_floats = 0;     // Lframe carried across the batches of a frame (one plane set, shared)
-    hipStream_t stream3 = nullptr, stream4 = nullptr;
-    hipEvent_t evLane[2][3] = {};              // per lane: fork, join, resolve done
+    hipStream_t laneStream[kMaxLanes][2] = {};  // lanes >= 1: main and side stream (lane 0 uses stream / stream2)
+    hipEvent_t evLane[kMaxLanes][3] = {};      // per lane: fork, join, resolve done
     hipEvent_t evStage = nullptr;
     int* wf_ovf = nullptr;                     // wide walker stack overflow area (allocated on first use)
     float* split_mem = nullptr; size_t split_floats = 0;    // fused kernel in sample groups: per-sample radiance + staged reservoirs
@@ -492,7 +498,7 @@ void free_present(DeviceState& d)
 
 void free_workspace(DeviceState& d)
 {
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < kMaxLanes; j++)
     {
         if (d.wf_mem[j]) (void)hipFree(d.wf_mem[j]);
         if (d.wf_cnt[j]) (void)hipFree(d.wf_cnt[j]);
@@ -1131,22 +1137,25 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
 #else
     // ... a frame that fits one batch is cut in two only while each half still fills the machine (measured: halves of 16.6 M paths
     // config 3 -5.5 %, config 4 +-0; halves of 8.3 M paths config 5 +13 %)
-    constexpr long long kMinHalfBatchPaths = 1ll << 24;
+    constexpr long long kMinHalfBatchPaths = 12000000;
     const bool severalBatches = sb < spp;
     const bool halves = !severalBatches && spp >= 2 && (long long)((spp + 1) / 2) * g.nOrd >= kMinHalfBatchPaths;
-    const int nLanes = (severalBatches || halves) ? 2 : 1;
+    const int nBatchesNatural = (int)((spp + sb - 1) / sb);
+    const int nLanes = severalBatches ? std::min(kBatchLanes, nBatchesNatural) : (halves ? std::min(kBatchLanes, 2) : 1);
 #endif
-    if (nLanes == 2 && sb > (spp + 1) / 2) sb = (spp + 1) / 2;
+    if (nLanes >= 2 && !severalBatches && sb > (spp + 1) / 2) sb = (spp + 1) / 2;
     const long long batchPaths = sb * (long long)g.nOrd;
     const int nRanges = (int)((batchPaths + kRange - 1) / kRange);
     const long long cap = (long long)nRanges * kRange;
-    WfBuffers Wl[2];
+    WfBuffers Wl[kMaxLanes];
     for (int j = 0; j < nLanes; j++) { int rc = ensure_workspace(c, d, j, cap, g.nOrd, nRanges, k.maxDepth, Wl[j]); if (rc != HRT_OK) return rc; }
-    hipStream_t laneMain[2] = {d.stream, d.stream3}, laneSide[2] = {d.stream2, d.stream4};
-    if (nLanes == 2)
-    {   // lane 1 starts behind everything enqueued so far (this frame's primary launch, the previous frame)
+    hipStream_t laneMain[kMaxLanes], laneSide[kMaxLanes];
+    laneMain[0] = d.stream; laneSide[0] = d.stream2;
+    for (int j = 1; j < kMaxLanes; j++) { laneMain[j] = d.laneStream[j][0]; laneSide[j] = d.laneStream[j][1]; }
+    if (nLanes >= 2)
+    {   // the other lanes start behind everything enqueued so far (this frame's primary launch, the previous frame)
         HIPCHK(c, hipEventRecord(d.evStage, d.stream));
-        HIPCHK(c, hipStreamWaitEvent(d.stream3, d.evStage, 0));
+        for (int j = 1; j < nLanes; j++) HIPCHK(c, hipStreamWaitEvent(laneMain[j], d.evStage, 0));
     }
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
     // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
@@ -1162,7 +1171,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     {
         void* v = nullptr;
         HIPCHK(c, hipMalloc(&v, (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));
-        d.wf_ovf = (int*)v; Wl[0].ovf = d.wf_ovf; Wl[1].ovf = d.wf_ovf;
+        d.wf_ovf = (int*)v; for (int j = 0; j < kMaxLanes; j++) Wl[j].ovf = d.wf_ovf;
     }
 #else
     constexpr bool wide = false;
@@ -1268,13 +1277,13 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
             }
         }
         // ordered part: Lframe is summed in sample order and resCur keeps its last writer, so a batch resolves after its predecessor
-        if (batch > 0 && nLanes == 2) HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[1 - lane][2], 0));
+        if (batch > 0 && nLanes >= 2) HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[(batch - 1) % nLanes][2], 0));
         hipLaunchKernelGGL(hrt_wf_resolve_kernel, gridP, block, 0, sMain, k, g, d.gb, d.fb, resCur, W);
         HIPCHK(c, hipGetLastError());
-        if (nLanes == 2) HIPCHK(c, hipEventRecord(d.evLane[lane][2], sMain));
+        if (nLanes >= 2) HIPCHK(c, hipEventRecord(d.evLane[lane][2], sMain));
     }
     // the frame ends on the device's main stream: the resolves form one chain, so its last link covers every batch of both lanes
-    if (nLanes == 2 && batch > 1) HIPCHK(c, hipStreamWaitEvent(d.stream, d.evLane[1][2], 0));
+    if (nLanes >= 2 && batch > 1 && (batch - 1) % nLanes != 0) HIPCHK(c, hipStreamWaitEvent(d.stream, d.evLane[(batch - 1) % nLanes][2], 0));
     return HRT_OK;
 }
 
@@ -1326,9 +1335,9 @@ try {
         if (err == hipSuccess) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d.device_id) == hipSuccess && cu > 0) d.n_cu = cu; }
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
-        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream3, hipStreamNonBlocking);
-        if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream4, hipStreamNonBlocking);
-        for (int j = 0; j < 2 && err == hipSuccess; j++)
+        for (int j = 1; j < kBatchLanes && err == hipSuccess; j++)
+            for (int e = 0; e < 2 && err == hipSuccess; e++) err = hipStreamCreateWithFlags(&d.laneStream[j][e], hipStreamNonBlocking);
+        for (int j = 0; j < kMaxLanes && err == hipSuccess; j++)
             for (int e = 0; e < 3 && err == hipSuccess; e++) err = hipEventCreateWithFlags(&d.evLane[j][e], hipEventDisableTiming);
         if (err == hipSuccess) err = hipEventCreateWithFlags(&d.evStage, hipEventDisableTiming);
         for (int f = 0; f < DeviceState::kRing && err == hipSuccess; f++)
@@ -1372,8 +1381,9 @@ void hrt_destroy(hrt_ctx* c)
         if (d.counters) (void)hipFree(d.counters);
         for (int f = 0; f < DeviceState::kRing; f++)
             for (int k = 0; k < 4; k++) if (d.ev[f][k]) (void)hipEventDestroy(d.ev[f][k]);
-        for (hipStream_t st : {d.stream2, d.stream3, d.stream4}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-        for (int j = 0; j < 2; j++) for (int e = 0; e < 3; e++) if (d.evLane[j][e]) (void)hipEventDestroy(d.evLane[j][e]);
+        if (d.stream2) { (void)hipStreamSynchronize(d.stream2); (void)hipStreamDestroy(d.stream2); }
+        for (int j = 1; j < kMaxLanes; j++) for (int e = 0; e < 2; e++) if (d.laneStream[j][e]) { (void)hipStreamSynchronize(d.laneStream[j][e]); (void)hipStreamDestroy(d.laneStream[j][e]); }
+        for (int j = 0; j < kMaxLanes; j++) for (int e = 0; e < 3; e++) if (d.evLane[j][e]) (void)hipEventDestroy(d.evLane[j][e]);
         if (d.evStage) (void)hipEventDestroy(d.evStage);
         if (d.stream) (void)hipStreamDestroy(d.stream);
     }
