@@ -141,6 +141,11 @@ hrt_wf_shade_kernel(FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long lo
                                                // Fewer rays in flight, but their tree nodes stay in L1 / L2: 3 / 4 / 5 / 6 / 8 / 12 measured
 #endif
 constexpr int kWalkBlocksPerCU = HRT_WALK_BLOCKS_PER_CU;
+#ifndef HRT_WALK_BLOCKS_PER_CU_2LANES
+#define HRT_WALK_BLOCKS_PER_CU_2LANES 2        // ... per lane when two sample batches are in flight: 2 / 3 / 4 / 6 measured on configs 4 / 5 at 64 / 256 spp:
+                                               // 314 / 322 / 328 / 342 ms and 1287 / 1298 / 1318 / 1387 ms
+#endif
+constexpr int kWalkBlocksPerCU2 = HRT_WALK_BLOCKS_PER_CU_2LANES;
 // Walk launches either give every wave one path range (static) or let persistent waves pull ranges until none is
 // left (chained, RangeGrab).  Measured, path stage of configs 3 / 4 / 5: static 33.5 / 56.4 / 32.8 ms, chained
 // 36.2 / 37.2 / 21.7 ms: the triangle scenes gain 1.5x from full lanes, the sphere-instance scene is bound by L1
@@ -1159,7 +1164,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     }
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
     // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
-    const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * kWalkBlocksPerCU));
+    const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * (nLanes >= 2 ? kWalkBlocksPerCU2 : kWalkBlocksPerCU)));
     // wide walker (experiment, HRT_WIDE=1 at upload and render time; production frames only): needs the collapsed trees and a
     // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
     static const int wideEnv = HRT_ENV("HRT_WIDE") ? atoi(HRT_ENV("HRT_WIDE")) : 0;
