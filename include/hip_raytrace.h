@@ -273,8 +273,9 @@ int  hrt_frame_times(hrt_ctx* ctx, int dev, int launch, float* ms, int cap, int*
 int  hrt_host_register(hrt_ctx* ctx, void* ptr, int64_t bytes);
 int  hrt_host_unregister(hrt_ctx* ctx, void* ptr);
 
-/* Caps the path-state workspace of the streamed pipeline at max_resident_paths paths (320 bytes each; 0 = the default of
- * 2^25 paths = 10.7 GB): frames whose width*height*spp exceeds it run in several sample batches, with identical results.
+/* Caps a path-state workspace of the streamed pipeline at max_resident_paths paths (324 bytes each; 0 = the default of
+ * 2^25 paths = 10.9 GB): frames whose width*height*spp exceeds it run in several sample batches, with identical results.
+ * Two sample batches are in flight at a time, each in a workspace of its own, so up to twice that much memory is held.
  * Counterpart of sizing MemoryBuffer1D allocations in the reference (Framebuffer.cs:60-97). */
 int  hrt_set_workspace_limit(hrt_ctx* ctx, int64_t max_resident_paths);
 
