@@ -380,7 +380,7 @@ def roofline_of(res, pmc, pmc_src, world):
            "algorithmic_note": "SURVEY 8d figure (reference struct sizes x work counters: every node / primitive fetch priced as memory traffic); "
                                "informational only -- the trees are cache-resident, this is not HBM traffic and is never used as frac",
            "pmc_source": pmc_src}
-    if pmc is not None and world == 1 and launch_s > 0:
+    if pmc is not None and launch_s > 0:
         stg = pmc["stage"]
         insts = stg.get("SQ_INSTS_VALU", 0.0)
         achieved = insts / launch_s / 1e9
@@ -394,13 +394,13 @@ def roofline_of(res, pmc, pmc_src, world):
         traffic = stg.get("hbm_read_bytes", 0.0) + stg.get("hbm_write_bytes", 0.0)
         out["traffic"] = int(traffic)
         gbs = traffic / launch_s / 1e9
-        out["hbm"] = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+        out["hbm"] = {"achieved": round(gbs, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(gbs / (HBM_PEAK_GBS * world), 5),
                       "read_bytes": int(stg.get("hbm_read_bytes", 0.0)), "write_bytes": int(stg.get("hbm_write_bytes", 0.0)),
-                      "compulsory_bytes": int(compulsory), "compulsory_frac_of_peak": round(compulsory / launch_s / 1e9 / HBM_PEAK_GBS, 5),
+                      "compulsory_bytes": int(compulsory), "compulsory_frac_of_peak": round(compulsory / launch_s / 1e9 / (HBM_PEAK_GBS * world), 5),
                       "traffic_over_compulsory": round(traffic / max(1.0, compulsory), 2)}
         out["kernels_priced"] = stg.get("kernels")
     else:
-        out["note"] = "PMC counters unavailable for this run (N > 1, or no rocprofv3 and no committed profile): frac not computed"
+        out["note"] = "PMC counters unavailable for this run (no rocprofv3 and no committed profile): frac not computed"
     return out
 
 
@@ -449,10 +449,14 @@ def main():
     # PMC passes first: child processes, before this process touches the GPU
     pmc = None
     pmc_src = {"kind": "none"}
-    if world == 1:
+    if rank == 0:
+        # N = 1: measured now.  N > 1: the committed N = 1 counts (the instructions of a frame do not depend on how its strips are
+        # dealt to the ranks, up to the sample-group split of small tiles), priced against N x the peak
         pmc_dir = os.path.join(ROOT, "gpurun_out", "bench_pmc_config%d" % args.config)
         have_gpu = os.path.exists("/dev/kfd")
-        pmc, pmc_src = pmc_for(args.config, args.spp, args.pmc == "auto" and have_gpu, pmc_dir)
+        pmc, pmc_src = pmc_for(args.config, args.spp, world == 1 and args.pmc == "auto" and have_gpu, pmc_dir)
+        if world > 1 and pmc is not None:
+            pmc_src = dict(pmc_src, note="counts of the N = 1 frame; at N > 1 they are spread over the ranks")
         if args.save_pmc and pmc is not None and pmc_src.get("kind") != "file":
             raw = dict(pmc["raw"], config=args.config, spp=args.spp or None, sources_sha1=sources_sha1(),
                        note="per-kernel sums per frame; FETCH_SIZE / WRITE_SIZE in KiB (hbm_*_bytes = x1024); rocprofv3 --pmc passes of `bench.py --pmc-child`")

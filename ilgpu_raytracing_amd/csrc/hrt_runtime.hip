@@ -1175,9 +1175,10 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     if (wide && !d.wf_ovf)
     {
         void* v = nullptr;
-        HIPCHK(c, hipMalloc(&v, (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));
-        d.wf_ovf = (int*)v; for (int j = 0; j < kMaxLanes; j++) Wl[j].ovf = d.wf_ovf;
+        HIPCHK(c, hipMalloc(&v, (size_t)kMaxLanes * 2 * (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));      // one area per lane and walk kind
+        d.wf_ovf = (int*)v;
     }
+    if (wide) for (int j = 0; j < kMaxLanes; j++) Wl[j].ovf = d.wf_ovf + (size_t)j * 2 * (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf;
 #else
     constexpr bool wide = false;
     (void)wideEnv;
@@ -1330,7 +1331,8 @@ try {
     else ids.push_back(0);
     for (int id : ids)
         if (id < 0 || id >= avail) return fail(nullptr, HRT_ERR_INVALID_ARG, "hrt_create: device id out of range");
-    hrt_ctx* c = new hrt_ctx();
+    struct CtxGuard { hrt_ctx* p; ~CtxGuard() { if (p) hrt_destroy(p); } } guard{new hrt_ctx()};      // an exception below must not leak the context
+    hrt_ctx* c = guard.p;
     c->dev.resize(ids.size());
     for (size_t i = 0; i < ids.size(); i++)
     {
@@ -1351,8 +1353,7 @@ try {
         if (err != hipSuccess)
         {
             std::string m = std::string("hrt_create: ") + hipGetErrorString(err);
-            hrt_destroy(c);
-            return fail(nullptr, HRT_ERR_HIP, m);
+            return fail(nullptr, HRT_ERR_HIP, m);           // the guard destroys the half-made context
         }
     }
     for (size_t i = 0; i < ids.size(); i++)
@@ -1363,6 +1364,7 @@ try {
                 hipError_t pe = hipDeviceEnablePeerAccess(ids[j], 0);
                 if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
             }
+    guard.p = nullptr;
     *out = c;
     return HRT_OK;
 }

@@ -1,0 +1,77 @@
+"""Round-2 additions to the boundary: per-frame event times, page-locked gather targets, the workspace limit, and the second
+(device-built) tree that boolean queries of fast-sphere scenes walk."""
+import numpy as np
+import pytest
+
+from ilgpu_raytracing_amd import _types as T, engine, scenes
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(cfg, w, h, spp):
+    return scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+
+
+def test_frame_times_and_registered_gather_targets(hrt_lib):
+    r = engine.RTRenderer([0])
+    try:
+        s = engine.Scene(); scenes.build_config2(s); r.commit(s)
+        cfg = scenes.CONFIGS[2]
+        w, h = 320, 184
+        p = _params(cfg, w, h, 2)
+        for _ in range(5):
+            r.render_params(p, None, flags=T.FLAG_NO_SYNC)
+        st = r.synchronize()
+        t0, t1 = r.frame_times(0), r.frame_times(1)
+        assert st.frames == 5 and len(t0) == 5 and len(t1) == 5 and np.all(t1 > 0) and np.all(t0 > 0)
+        assert abs(float(t1.sum()) - st.kernel_ms[1]) < 1e-3 * max(1.0, st.kernel_ms[1])
+        a, oa = T.alloc_outputs(w, h, ["color", "depth", "objectId", "radiance"])
+        r.render_params(p, oa)
+        b, ob = T.alloc_outputs(w, h, ["color", "depth", "objectId", "radiance"])
+        r.register_host(b)
+        with pytest.raises(engine.HrtError):
+            r.register_host(b)                                       # the same range twice
+        r.render_params(p, ob)
+        H.assert_outputs_equal(a, b)
+        r.unregister_host(b)
+        with pytest.raises(engine.HrtError):
+            r.unregister_host(b)                                     # no longer registered
+        r.render_params(p, ob)                                       # still a valid (pageable) target
+        H.assert_outputs_equal(a, b)
+        with pytest.raises(engine.HrtError):
+            r.set_workspace_limit(-1)
+        assert b"gfx950" in hrt_lib.hrt_version()
+    finally:
+        r.close()
+
+
+def test_boolean_queries_on_the_second_tree_change_nothing(orc, hrt_lib):
+    """600 fast-sphere instances: the production frame walks the device-built tree for shadow rays and the last bounce
+    (hrt_walker.hpp, ALT), the counting frame walks the uploaded tree for everything, the oracle restates the reference: all three
+    agree bit for bit; and they still do after a scene update has dropped the second tree."""
+    def build(b):
+        scenes.build_random_spheres(b, 599, seed=0x1234567, extent=6.0)
+    cfg = scenes.Config("any", 0, 0, 0, (0.0, 3.0, 11.0), (0.0, 0.8, 0.0))
+    w, h, spp = 256, 144, 3
+    ref, ost, _ = H.oracle_frame(orc, build, cfg, w, h, spp)
+    r = engine.RTRenderer([0])
+    try:
+        s = engine.Scene(); build(s); r.commit(s)
+        p = _params(cfg, w, h, spp)
+        prod, op = T.alloc_outputs(w, h)
+        r.render_params(p, op, flags=T.FLAG_STREAMED)
+        H.assert_outputs_equal(ref, prod)
+        r.reset_history()
+        cnt, oc = T.alloc_outputs(w, h)
+        st = r.render_params(p, oc, flags=T.FLAG_STREAMED | T.FLAG_COUNTERS)
+        H.assert_outputs_equal(ref, cnt)
+        assert st.k[1].as_dict() == ost.k[1].as_dict()
+        # a refit that moves nothing: the second tree is dropped, the picture stays
+        r.update_instances([], [], T.REBUILD_FORCE_REFIT)
+        r.reset_history()
+        again, oa = T.alloc_outputs(w, h)
+        r.render_params(p, oa, flags=T.FLAG_STREAMED)
+        H.assert_outputs_equal(ref, again)
+    finally:
+        r.close()
