@@ -53,6 +53,7 @@ HRT_D F3 cross(F3 a, F3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 // corrections hipcc emits for sqrtf (-fhip-fp32-correctly-rounded-divide-sqrt), minus the rescaling of tiny arguments and
 // the class test for infinities -- 7 of its 17 instructions.  tests/test_math_gpu.py compares it with hrt_sqrt over every
 // argument the sampler below can produce and over [1e-20, 1e20].
+template <bool NONZERO = false>       // NONZERO: the caller knows x != 0 (the zero select is dropped)
 HRT_D float sqrt_normal_range(float x)
 {
     const float s = __builtin_amdgcn_sqrtf(x);
@@ -60,7 +61,7 @@ HRT_D float sqrt_normal_range(float x)
     const float rDn = __builtin_fmaf(-sDn, s, x), rUp = __builtin_fmaf(-sUp, s, x);
     float r = (rDn <= 0.f) ? sDn : s;
     r = (rUp > 0.f) ? sUp : r;
-    return (x == 0.f) ? x : r;
+    return (!NONZERO && x == 0.f) ? x : r;
 }
 // hrt_rsqrt(x) = 1 / sqrt(x), both IEEE, for x = max(1e-20, .): x in [2^-67, +inf], never NaN -- the argument of every
 // Normalize (Float3.cs:91-95).  sqrt: the trimmed form above.  1 / s with s in [2^-34, 2^64]: the division sequence hipcc
@@ -68,9 +69,10 @@ HRT_D float sqrt_normal_range(float x)
 // quotient are normal numbers far from the exponent limits), the scaling half of v_div_fmas and the special-case v_div_fixup,
 // of which only s = +inf (|v|^2 overflowed) remains and is handled by the select.  16 instructions instead of 28;
 // tests/test_math_gpu.py compares it with hrt_rsqrt on the device for EVERY float in the domain.
+template <bool FINITE = false>        // FINITE: the caller knows x < +inf (the select for s = +inf is dropped)
 HRT_D float rsqrt_clamped(float x)
 {
-    const float s = sqrt_normal_range(x);
+    const float s = sqrt_normal_range<true>(x);
     const float r0 = __builtin_amdgcn_rcpf(s);
     const float e0 = __builtin_fmaf(-s, r0, 1.f);
     const float r1 = __builtin_fmaf(e0, r0, r0);
@@ -78,11 +80,12 @@ HRT_D float rsqrt_clamped(float x)
     const float q1 = __builtin_fmaf(e1, r1, r1);
     const float e2 = __builtin_fmaf(-s, q1, 1.f);
     const float q = __builtin_fmaf(e2, r1, q1);
-    return (s == __builtin_inff()) ? 0.f : q;
+    return (!FINITE && s == __builtin_inff()) ? 0.f : q;
 }
+template <bool FINITE = false>
 HRT_D F3 normalize(F3 v)   // Float3.cs:91-95
 {
-    float inv = rsqrt_clamped(hrt_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z));
+    float inv = rsqrt_clamped<FINITE>(hrt_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z));
     return mk3(v.x * inv, v.y * inv, v.z * inv);
 }
 HRT_D F3 inv_dir(F3 d)     // RTRay.cs:548-549
@@ -104,7 +107,10 @@ struct Rng {
     {
         uint32_t x = s;
         x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-        s = (x != 0u) ? x : 1u;
+        // The reference's "x != 0 ? x : 1" (RTUtils.cs:40) can never fire: each of the three steps is an invertible linear map of
+        // GF(2)^32, so x == 0 only from s == 0, and s is never 0 (Create maps a zero seed to 1, the seed mixer ORs in 1, :28,:96).
+        // tests/test_oracle_kat.py checks the rank of the map.
+        s = x;
         return s;
     }
     HRT_D float next_f() { return (float)(next_u() & 0x00FFFFFFu) * (1.0f / 16777216.0f); }
@@ -699,25 +705,44 @@ HRT_D F3 sample_hemisphere_cosine(const Frame& f, Rng& rng)
 {
     float r1 = rng.next_f(), r2 = rng.next_f();          // k / 2^24: r2 is 0 or >= 2^-24, 1 - r2 is >= 2^-24
     float phi = 2.f * kPI * r1;
-    float cosTheta = sqrt_normal_range(1.f - r2);
+    float cosTheta = sqrt_normal_range<true>(1.f - r2);
     float sinTheta = sqrt_normal_range(r2);
     float sn, cs;
-    hrt_sincos(phi, &sn, &cs);                   // == hrt_sin(phi), hrt_cos(phi); both polynomials once, no divergent branch
+    hrt_sincos_nonneg(phi, &sn, &cs);            // == hrt_sin(phi), hrt_cos(phi) for phi >= 0; both polynomials once, no divergent branch
     float x = cs * sinTheta;
     float y = sn * sinTheta;
     float z = cosTheta;
     F3 v = f.t * x + f.b * y + f.n * z;
-    return normalize(v);
+    // |x|, |y|, z <= 1 and the frame vectors are outputs of normalize / a cross product of two of them (components <= 2, or NaN):
+    // |v|^2 < 100 or NaN, and max(1e-20, NaN) = 1e-20 -- the sum of squares is never +inf
+    return normalize<true>(v);
 }
 
 // ------------------------------------------------------------------ ReSTIR-DI (RTRay.cs:330-543)
-struct Res { F3 L, wi; float pdf, w, wSum; int m, lightId; };
+// The reservoir's L and pdf fields are not carried through the candidate stream: every update site stores values that are
+// functions of the accepted (wi, lightId) and the vertex normal alone --
+//   L   = lightId == 2 ? dirLightRadiance : SkyWeighted(wi)                                    (:455,:467,:421)
+//   pdf = lightId == 2 ? max(EPS, mixDelta) : max(EPS, CosHemispherePdf(n, wi) * mixLocal)     (:466,:424-426; for a local
+//         candidate :453-454 writes max(EPS, max(EPS, c) * mixLocal), the same number: c >= EPS makes the two expressions
+//         identical, c < EPS makes both EPS because mixLocal < 1)
+// -- so res_L / res_pdf evaluate them once, where a reservoir is stored.  "Never accepted" (L = 0, pdf = 0, the defaults of
+// :330-334) is w == 0: an accepted score is > 0 (acceptP = score / newSum has to exceed a draw >= 0 with newSum > 0).
+struct Res { F3 wi; float w, wSum; int m, lightId; };
 
-HRT_D void reservoir_update(Res& r, F3 wi, float pdfSel, F3 Li, float score, int lightId, Rng& rng)   // :394-405 (multiplicity 1)
+HRT_D F3 res_L(const FrameK& k, F3 wi, float w, int lightId)
+{
+    return w > 0.f ? (lightId == 2 ? cv3(k.dirLightRadiance) : sky(k, wi)) : mk3(0.f, 0.f, 0.f);
+}
+HRT_D float res_pdf(F3 n, const Res& r)
+{
+    return r.w > 0.f ? (r.lightId == 2 ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(n, r.wi) * (8.f / 9.f))) : 0.f;
+}
+
+HRT_D void reservoir_update(Res& r, F3 wi, float score, int lightId, Rng& rng)   // :394-405 (multiplicity 1)
 {
     float newSum = r.wSum + score;
     float acceptP = (newSum > 0.f) ? score / newSum : 0.f;
-    if (rng.next_f() < acceptP) { r.wi = wi; r.pdf = pdfSel; r.L = Li; r.w = score; r.lightId = lightId; }
+    if (rng.next_f() < acceptP) { r.wi = wi; r.w = score; r.lightId = lightId; }
     r.wSum = newSum;
     r.m = r.m + 1;
 }
@@ -767,7 +792,7 @@ HRT_D void import_prev(const FrameK& k, const DGBuffer& gb, const DReservoir& pr
     F3 f_over_p = albedo * LiImp * ((nl / pdfHere) * kINV_PI);
     float sHere = luminance(f_over_p);
     float Wsrc = pwSum / ((float)hrt_imax(1, pm) * hrt_fmax(kEPS_MIN, pw));
-    reservoir_update(r, wi, pdfHere, LiImp, sHere * Wsrc, lid, rng);
+    reservoir_update(r, wi, sHere * Wsrc, lid, rng);
 }
 
 // candidate generation + reuse of ReSTIR_Direct (:449-516); the final visibility ray is
@@ -780,7 +805,7 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
     const float mixLocal = 8.f / 9.f;     // (float)8/(float)9 , :446
     const float mixDelta = 1.f / 9.f;
     F3 n = fr.n;
-    Res r; r.L = mk3(0.f, 0.f, 0.f); r.wi = mk3(0.f, 0.f, 0.f); r.pdf = 0.f; r.w = 0.f; r.wSum = 0.f; r.m = 0; r.lightId = 0;
+    Res r; r.wi = mk3(0.f, 0.f, 0.f); r.w = 0.f; r.wSum = 0.f; r.m = 0; r.lightId = 0;
     // kept rolled: unrolled 8x the candidate body alone is ~3000 instructions (24 KB), a third of the instruction cache
     // two CUs share; the loop-carried state is a handful of registers
 #pragma unroll 1
@@ -792,7 +817,7 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
         float pdfSel = hrt_fmax(kEPS_MIN, pdfLocal * mixLocal);
         F3 LiLoc = sky(k, wi);
         F3 f_over_p = albedo * LiLoc * ((nl / pdfSel) * kINV_PI);
-        reservoir_update(r, wi, pdfSel, LiLoc, luminance(f_over_p), 1, rng);
+        reservoir_update(r, wi, luminance(f_over_p), 1, rng);
     }
     {
         F3 wi = normalize(cv3(k.dirLightDir));
@@ -800,7 +825,7 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
         float pdfSel = hrt_fmax(kEPS_MIN, mixDelta);
         F3 LiDir = cv3(k.dirLightRadiance);
         F3 f_over_p = albedo * LiDir * ((nl / pdfSel) * kINV_PI);
-        reservoir_update(r, wi, pdfSel, LiDir, luminance(f_over_p), 2, rng);
+        reservoir_update(r, wi, luminance(f_over_p), 2, rng);
     }
     if (allowReuse && k.enableTemporal != 0)
     {
@@ -909,9 +934,10 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             I = normalize(pos - cv3(k.cam.origin));
         };
         // resCur.Write (:42-47): every sample's first diffuse vertex writes the same slot and only the last write survives.
-        // The latest one waits in the lane's own LDS column (11 dwords, [field][thread]: conflict-free) instead of 11 registers
-        // held across the whole bounce loop, and is stored once after the sample loop ((spp-1) x 44 B/pixel of HBM writes saved).
-        __shared__ float s_res[11][256];
+        // The latest one waits in the lane's own LDS column (8 dwords, [field][thread]: conflict-free; L is a function of the
+        // others, res_L) instead of registers held across the whole bounce loop, and is stored once after the sample loop
+        // ((spp-1) x 44 B/pixel of HBM writes saved).
+        __shared__ float s_res[8][256];
         bool haveRes = false;
 
         // Lanes do not wait for each other at sample boundaries: every lane runs its own (sample, depth)
@@ -1003,8 +1029,8 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                     if (!wroteReservoir)
                     {
                         const int t = threadIdx.x;
-                        s_res[0][t] = r.L.x; s_res[1][t] = r.L.y; s_res[2][t] = r.L.z; s_res[3][t] = r.wi.x; s_res[4][t] = r.wi.y; s_res[5][t] = r.wi.z;
-                        s_res[6][t] = r.pdf; s_res[7][t] = r.w; s_res[8][t] = r.wSum; s_res[9][t] = __int_as_float(r.m); s_res[10][t] = __int_as_float(r.lightId);
+                        s_res[0][t] = r.wi.x; s_res[1][t] = r.wi.y; s_res[2][t] = r.wi.z; s_res[3][t] = res_pdf(nrm, r);
+                        s_res[4][t] = r.w; s_res[5][t] = r.wSum; s_res[6][t] = __int_as_float(r.m); s_res[7][t] = __int_as_float(r.lightId);
                         haveRes = true;
                         wroteReservoir = true;
                     }
@@ -1059,16 +1085,20 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
             if (haveRes)
             {
                 const int t = threadIdx.x;
+                const F3 wi = mk3(s_res[0][t], s_res[1][t], s_res[2][t]);
+                const F3 L = res_L(k, wi, s_res[4][t], __float_as_int(s_res[7][t]));
+                st[0] = L.x; st[P] = L.y; st[2 * P] = L.z; st[3 * P] = wi.x; st[4 * P] = wi.y; st[5 * P] = wi.z;
 #pragma unroll
-                for (int f = 0; f < 11; f++) st[f * P] = s_res[f][t];
+                for (int f = 3; f < 8; f++) st[(f + 3) * P] = s_res[f][t];       // pdf, w, wSum, m, lightId
             }
         }
         else if (haveRes)
         {
             const int t = threadIdx.x;
-            resCur.L[index] = to3(mk3(s_res[0][t], s_res[1][t], s_res[2][t])); resCur.wi[index] = to3(mk3(s_res[3][t], s_res[4][t], s_res[5][t]));
-            resCur.pdf[index] = s_res[6][t]; resCur.w[index] = s_res[7][t]; resCur.wSum[index] = s_res[8][t];
-            resCur.lightId[index] = __float_as_int(s_res[10][t]); resCur.m[index] = __float_as_int(s_res[9][t]);
+            const F3 wi = mk3(s_res[0][t], s_res[1][t], s_res[2][t]);
+            resCur.L[index] = to3(res_L(k, wi, s_res[4][t], __float_as_int(s_res[7][t]))); resCur.wi[index] = to3(wi);
+            resCur.pdf[index] = s_res[3][t]; resCur.w[index] = s_res[4][t]; resCur.wSum[index] = s_res[5][t];
+            resCur.lightId[index] = __float_as_int(s_res[7][t]); resCur.m[index] = __float_as_int(s_res[6][t]);
         }
     }
     if (SPLIT) return;

@@ -285,6 +285,10 @@ __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float
     case 21: { float s, c; hrt_sincos(a, &s, &c); r = c; } break;
     case 22: r = sqrt_normal_range(a); break;
     case 23: r = rsqrt_clamped(a); break;
+    case 24: { float s, c; hrt_sincos_nonneg(a, &s, &c); r = s; } break;
+    case 25: { float s, c; hrt_sincos_nonneg(a, &s, &c); r = c; } break;
+    case 26: r = sqrt_normal_range<true>(a); break;
+    case 27: r = rsqrt_clamped<true>(a); break;
     }
     out[i] = r;
 }

@@ -72,7 +72,7 @@ enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROT
 // SQ_A = (o.xyz, d.x)  SQ_B = (d.yz, slot in range, add.x): 16-byte records; add.yz in two planes
 enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_VIS = 10, S_PLANES = 11 };      // S_VIS: 1 once the walk found the request unoccluded
 // reservoir staging per path id
-enum { G_L = 0, G_WI = 3, G_PDF = 6, G_W = 7, G_WSUM = 8, G_M = 9, G_LID = 10, G_FLAG = 11, G_PLANES = 12 };
+enum { G_WI = 0, G_PDF = 3, G_W = 4, G_WSUM = 5, G_M = 6, G_LID = 7, G_FLAG = 8, G_PLANES = 9 };     // L is res_L(wi, w, lightId): not staged
 
 struct WfBuffers {
     Planes A, B, R, SQ;          // stride = cap
@@ -275,7 +275,7 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
                 }
                 if (!(flg & RF_WROTE))
                 {   // first diffuse vertex of this sample: stage the reservoir (resCur.Write :292-296)
-                    W.stage.st3(G_L, pid, r.L); W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, r.pdf);
+                    W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, res_pdf(nrm, r));
                     W.stage.stf(G_W, pid, r.w); W.stage.stf(G_WSUM, pid, r.wSum); W.stage.sti(G_M, pid, r.m);
                     W.stage.sti(G_LID, pid, r.lightId); W.stage.sti(G_FLAG, pid, 1);
                     flg |= RF_WROTE;
@@ -625,9 +625,12 @@ HRT_D void wf_resolve_pixel(const FrameK& k, const WfGeom& g, const DGBuffer& gb
         if (winner >= 0)
         {
             long long pid = (long long)winner * g.nOrd + ord;
-            resCur.L[index] = to3(W.stage.ld3(G_L, pid)); resCur.wi[index] = to3(W.stage.ld3(G_WI, pid));
-            resCur.pdf[index] = W.stage.ldf(G_PDF, pid); resCur.w[index] = W.stage.ldf(G_W, pid);
-            resCur.wSum[index] = W.stage.ldf(G_WSUM, pid); resCur.lightId[index] = W.stage.ldi(G_LID, pid);
+            const F3 wi = W.stage.ld3(G_WI, pid);
+            const float w = W.stage.ldf(G_W, pid);
+            const int lid = W.stage.ldi(G_LID, pid);
+            resCur.L[index] = to3(res_L(k, wi, w, lid)); resCur.wi[index] = to3(wi);
+            resCur.pdf[index] = W.stage.ldf(G_PDF, pid); resCur.w[index] = w;
+            resCur.wSum[index] = W.stage.ldf(G_WSUM, pid); resCur.lightId[index] = lid;
             resCur.m[index] = W.stage.ldi(G_M, pid);
         }
     }

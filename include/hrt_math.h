@@ -152,6 +152,26 @@ HRT_HD void hrt_sincos(float xin, float* s, float* c)
     *c = cneg ? -rc : rc;
 }
 
+/* hrt_sincos for an argument the caller knows is >= 0 (or NaN / -0, for which the sign tests of hrt_sincos are false as well):
+ * the same expressions without the two sign tests. */
+HRT_HD void hrt_sincos_nonneg(float x, float* s, float* c)
+{
+    int j = (int)(HRT_FOPI * x);
+    float y = (float)j;
+    if (j & 1) { j += 1; y += 1.0f; }
+    j &= 7;
+    int sneg = 0, cneg = 0;
+    if (j > 3) { sneg = 1; cneg = 1; j -= 4; }
+    if (j > 1) cneg = !cneg;
+    x = ((x - y * HRT_DP1) - y * HRT_DP2) - y * HRT_DP3;
+    float z = x * x;
+    float sp = hrt__sin_poly(x, z), cp = hrt__cos_poly(z);
+    int sw = (j == 1 || j == 2);
+    float rs = sw ? cp : sp, rc = sw ? sp : cp;
+    *s = sneg ? -rs : rs;
+    *c = cneg ? -rc : rc;
+}
+
 HRT_HD float hrt_tan(float xin)
 {
     float sign = 1.0f;

@@ -61,6 +61,24 @@ def test_fused_sincos_equals_sin_and_cos(orc, renderer):
     assert np.array_equal(c_ref.view(np.uint32), c_got.view(np.uint32))
 
 
+def test_sampler_variants_equal_the_general_functions(orc, renderer):
+    """The cosine-hemisphere sampler calls variants that drop tests its arguments cannot need: hrt_sincos_nonneg (phi >= 0: no sign
+    tests), sqrt_normal_range<NONZERO> (1 - r2 >= 2^-24: no zero select), rsqrt_clamped<FINITE> (|v|^2 < 100: no select for +inf).
+    Each against the oracle's general function over every argument the sampler can produce / a wide sample of its domain."""
+    k = np.arange(0, 1 << 24, dtype=np.float32) * np.float32(1.0 / 16777216.0)
+    phi = (np.float32(2.0) * np.float32(3.14159265358979323846)) * k
+    rng = np.random.default_rng(17)
+    x = np.concatenate([phi, rng.uniform(0, 50, 200000).astype(np.float32)])
+    assert np.array_equal(orc.math_eval("sin", x).view(np.uint32), renderer.math_probe(24, x).view(np.uint32))
+    assert np.array_equal(orc.math_eval("cos", x).view(np.uint32), renderer.math_probe(25, x).view(np.uint32))
+    one_minus = (np.float32(1.0) - k).astype(np.float32)
+    wide = (10.0 ** rng.uniform(-20, 20, 2000000)).astype(np.float32)
+    for v in (one_minus, wide):
+        assert np.array_equal(orc.math_eval("sqrt", v).view(np.uint32), renderer.math_probe(26, v).view(np.uint32))
+    fin = np.maximum((10.0 ** rng.uniform(-20, 38, 2000000)).astype(np.float32), np.float32(1e-20))
+    assert np.array_equal(orc.math_eval("rsqrt", fin).view(np.uint32), renderer.math_probe(27, fin).view(np.uint32))
+
+
 def test_sqrt_normal_range_equals_ieee_sqrt(orc, renderer):
     """The trimmed square root of the hemisphere sampler against the IEEE one: EVERY k / 2^24 (both sampler arguments r2 and
     1 - r2 are of that form) and a wide sample of its stated domain."""

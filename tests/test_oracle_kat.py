@@ -416,3 +416,30 @@ def test_box_test_is_monotone_in_the_box(orc):
     child = orc.hit_box(o1, d1, [[1.0, 0.0, 0.0]], [[1.0, 5.0, 5.0]], [1e30])[0]
     parent = orc.hit_box(o1, d1, [[1.0, 0.0, 0.0]], [[2.0, 5.0, 5.0]], [1e30])[0]
     assert (child, parent) == (1, 0)
+
+
+def test_xorshift_step_is_a_bijection_and_keeps_zero_out():
+    """RTUtils.cs:33-42 guards the xorshift state with `x != 0 ? x : 1`.  The kernels drop the guard (hrt_device.hpp, Rng::next_u):
+    the step x ^= x << 13; x ^= x >> 17; x ^= x << 5 is a linear map of GF(2)^32 of full rank, so only a zero state yields zero, and
+    no state is ever zero (a zero seed becomes 1, the seed mixer ORs in 1)."""
+    def step(x):
+        x ^= (x << 13) & 0xFFFFFFFF
+        x ^= x >> 17
+        x ^= (x << 5) & 0xFFFFFFFF
+        return x
+    rows = [step(1 << i) for i in range(32)]            # images of the basis vectors
+    rank = 0
+    for bit in range(32):                                # Gaussian elimination over GF(2)
+        piv = next((i for i in range(rank, 32) if rows[i] >> bit & 1), None)
+        if piv is None:
+            continue
+        rows[rank], rows[piv] = rows[piv], rows[rank]
+        for i in range(32):
+            if i != rank and rows[i] >> bit & 1:
+                rows[i] ^= rows[rank]
+        rank += 1
+    assert rank == 32
+    rng = np.random.default_rng(5)
+    for x in [1, 0xFFFFFFFF, 0x80000000] + [int(v) for v in rng.integers(1, 2 ** 32, 2000)]:
+        a, b = int(rng.integers(1, 2 ** 32)), int(rng.integers(1, 2 ** 32))
+        assert step(x) != 0 and step(a ^ b) == step(a) ^ step(b)      # non-zero image, linearity
