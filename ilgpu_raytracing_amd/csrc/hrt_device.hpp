@@ -808,8 +808,11 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
     Res r; r.wi = mk3(0.f, 0.f, 0.f); r.w = 0.f; r.wSum = 0.f; r.m = 0; r.lightId = 0;
     // kept rolled: unrolled 8x the candidate body alone is ~3000 instructions (24 KB), a third of the instruction cache
     // two CUs share; the loop-carried state is a handful of registers
+#ifndef HRT_ABL_CAND
+#define HRT_ABL_CAND 8
+#endif
 #pragma unroll 1
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < HRT_ABL_CAND; i++)
     {
         F3 wi = sample_hemisphere_cosine(fr, rng);
         float nl = hrt_fmax(0.f, dot(n, wi));
@@ -920,15 +923,23 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
     }
     else
     {
-        const SeedBase sb = seed_base((uint32_t)px, (uint32_t)py, k.frame, 0xC0FFEEu, k.rngLockNoise);
+        // Everything a sample start needs from the pixel (seed halves, G-buffer addresses) is derived again from the pixel index
+        // behind an optimisation barrier, so that one register lives across the bounce loop instead of the ~17 the compiler would
+        // otherwise keep -- and, at 96 registers, spill to scratch memory (68 B per lane of HBM traffic).
+        auto fresh_index = [&]() { int i = index; asm volatile("" : "+v"(i)); return i; };
         // The G-buffer vertex every sample starts from (:221-230) is re-read from memory at each sample start (an L2
         // hit) instead of being held in 14 registers across the whole bounce loop.
         F3 pos, nrm, alb, I; int shade; float ior;
-        auto start_vertex = [&]() {
-            pos = ld3(&gb.worldPos[index]);
-            nrm = normalize(ld3(&gb.normalWS[index]));
-            alb = ld3(&gb.baseColor[index]);
-            const int packedMat = gb.matId[index];
+        Rng rng;
+        auto start_sample = [&](int sIdx) {
+            const int i = fresh_index();
+            const int w = hrt_imax(1, k.width);
+            const SeedBase sb = seed_base((uint32_t)(i % w), (uint32_t)(i / w), k.frame, 0xC0FFEEu, k.rngLockNoise);
+            rng = rng_for_sample(sb, (uint32_t)sIdx);
+            pos = ld3(&gb.worldPos[i]);
+            nrm = normalize(ld3(&gb.normalWS[i]));
+            alb = ld3(&gb.baseColor[i]);
+            const int packedMat = gb.matId[i];
             shade = packedMat & 0xFFFF;
             ior = (float)((packedMat >> 16) & 0xFFFF) / 1000.f;
             I = normalize(pos - cv3(k.cam.origin));
@@ -944,9 +955,8 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         // cursor through one flat bounce loop, so a lane whose path ended starts its next sample while its
         // neighbours are still bouncing.  Per-pixel order is untouched (samples of a pixel stay sequential).
         int s = sFirst, depth = 0;
-        Rng rng = rng_for_sample(sb, (uint32_t)sFirst);
         bool wroteReservoir = false;            // per sample (RTRay.cs:231): every sample's first diffuse vertex writes resCur
-        start_vertex();
+        start_sample(sFirst);
         F3 Li = mk3(0.f, 0.f, 0.f), T = mk3(1.f, 1.f, 1.f);
         if (k.maxDepth <= 0) { for (; s < spp; s++) add_sample(s, safe_color(Li)); }
 
@@ -1015,7 +1025,11 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                         {
                             PSTAT(4);
                             Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
+#ifdef HRT_ABL_NOSHADOW
+                            if (sray.o.x != 12345.f)
+#else
                             if (!tr.template occluded<COUNT>(sray, 1e29f, C))
+#endif
                             {
                                 float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
                                 F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
@@ -1050,6 +1064,9 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 {   // TraceNext :659-671 -- the one closest-hit site of the bounce loop
                     PSTAT(5);
                     Hit h;
+#ifdef HRT_ABL_CLOSEST2
+                    { Hit h2; Ray r2 = ray; r2.o.x += 1e-3f; if (tr.template closest<COUNT>(r2, h2, C)) T.x += h2.t * 1e-30f; }
+#endif
                     if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); ended = true; }
                     else
                     {
@@ -1069,9 +1086,8 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 s++;
                 if (s < spp)
                 {   // next sample starts again from the G-buffer vertex (:212-231)
-                    rng = rng_for_sample(sb, (uint32_t)s);
                     wroteReservoir = false;
-                    start_vertex();
+                    start_sample(s);
                     Li = mk3(0.f, 0.f, 0.f); T = mk3(1.f, 1.f, 1.f);
                     depth = 0;
                 }
@@ -1095,19 +1111,21 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
         else if (haveRes)
         {
             const int t = threadIdx.x;
+            const int i = fresh_index();
             const F3 wi = mk3(s_res[0][t], s_res[1][t], s_res[2][t]);
-            resCur.L[index] = to3(res_L(k, wi, s_res[4][t], __float_as_int(s_res[7][t]))); resCur.wi[index] = to3(wi);
-            resCur.pdf[index] = s_res[3][t]; resCur.w[index] = s_res[4][t]; resCur.wSum[index] = s_res[5][t];
-            resCur.lightId[index] = __float_as_int(s_res[7][t]); resCur.m[index] = __float_as_int(s_res[6][t]);
+            resCur.L[i] = to3(res_L(k, wi, s_res[4][t], __float_as_int(s_res[7][t]))); resCur.wi[i] = to3(wi);
+            resCur.pdf[i] = s_res[3][t]; resCur.w[i] = s_res[4][t]; resCur.wSum[i] = s_res[5][t];
+            resCur.lightId[i] = __float_as_int(s_res[7][t]); resCur.m[i] = __float_as_int(s_res[6][t]);
         }
     }
     if (SPLIT) return;
 
     F3 Lout = Lframe * (1.0f / (float)sppAll);
-    if (fb.radiance) fb.radiance[index] = to3(Lout);
-    fb.color[index] = pack_rgba8(Lout);
-    fb.depth[index] = cam_distance(k, ld3(&gb.worldPos[index]));
-    fb.objectId[index] = gb.objId[index];
+    int io = index; asm volatile("" : "+v"(io));          // addresses of the stores derived here, not carried through the loop
+    if (fb.radiance) fb.radiance[io] = to3(Lout);
+    fb.color[io] = pack_rgba8(Lout);
+    fb.depth[io] = cam_distance(k, ld3(&gb.worldPos[io]));
+    fb.objectId[io] = gb.objId[io];
 }
 
 // second half of a SPLIT frame: ordered sample sum (:320-324), reservoir of the last sample that reached a diffuse vertex
