@@ -344,7 +344,7 @@ struct DeviceState {
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     // a second tree over the same instances, built on the device at upload: what boolean queries of fast-sphere scenes walk
     TlasDevice tl2{};
-    void* tl2mem[14] = {};
+    void* tl2mem[15] = {};
     DPacked dpackedAny{};
     bool any_ok = false;
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
@@ -526,7 +526,7 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
-    for (int i = 0; i < 14; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+    for (int i = 0; i < 15; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
     d.tl2 = TlasDevice{}; d.any_ok = false;
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
@@ -562,6 +562,7 @@ struct PackedHost {
     bool blas_refit_ok = true;                               // every TriMesh BLAS can be refitted on the device
     bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
     int reach_leaves = 0;     // reachable TLAS leaves
+    bool inst_once = false;   // the reachable TLAS leaves list every instance exactly once (a second tree over "the instances" answers the same queries)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
 };
@@ -714,6 +715,23 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             }
         }
         if (nT == 0) out.refit_ok = false;
+        // does the walk meet every instance exactly once?
+        std::vector<uint8_t> seen((size_t)std::max<int64_t>(nI, 1), 0);
+        bool once = nT > 0 && out.refit_ok;
+        for (size_t i = 0; once && i < (size_t)nT; i++)
+        {
+            if (cntq(i) == 0 || !(reachableT < 0 || (int32_t)i < reachableT)) continue;
+            const int first = __builtin_bit_cast(int, out.tlas[i].lo.w);
+            for (int j = 0; j < cntq(i); j++)
+            {
+                const int64_t slot = (int64_t)first + j;
+                if (slot < 0 || slot >= nTI) { once = false; break; }
+                const int64_t ii = s->tlasInstanceIndices[slot];
+                if (ii < 0 || ii >= nI || seen[(size_t)ii]++) { once = false; break; }
+            }
+        }
+        for (int64_t ii = 0; once && ii < nI; ii++) if (!seen[(size_t)ii]) once = false;
+        out.inst_once = once;
     }
     alloc_nodes(nB, out.blas);
     {
@@ -1228,15 +1246,27 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                         }
                     hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, vsel, depth, chained, cnt1);
                 };
+                // with a second tree every production walk of the frame uses it, and so does the shading of their winners (leaf
+                // slots are the second tree's)
+                bool second = false;
+                TR trFin = tr;
+                if constexpr (F == 0) { second = d.any_ok && !count; if (second) trFin.P = d.dpackedAny; }
+#ifdef HRT_NO_ALT_CLOSEST        // A/B: closest-hit walks of the inner bounces on the uploaded tree
+                const bool secondClosest = false;
+                trFin = tr;
+#else
+                const bool secondClosest = second;
+#endif
                 auto launch_closest = [&](hipStream_t st) {
-                    if (!lastBounce) { hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1); return; }
                     if constexpr (F == 0)
-                        if (d.any_ok)
+                        if (lastBounce ? d.any_ok : secondClosest)
                         {
                             TR trAny = tr; trAny.P = d.dpackedAny;
-                            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, depth, chained, cnt1);
+                            if (lastBounce) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, depth, chained, cnt1);
+                            else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, false, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, depth, chained, cnt1);
                             return;
                         }
+                    if (!lastBounce) { hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1); return; }
                     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
                 };
                 if (count)
@@ -1263,13 +1293,13 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     launch_shadow(sSide);
                     HIPCHK(c, hipEventRecord(d.evLane[lane][1], sSide));
                     HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[lane][1], 0));
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trFin, k, W, vsel, depth);
                 }
                 else
                 {
                     launch_shadow(sMain);
                     launch_closest(sMain);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
+                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trFin, k, W, vsel, depth);
                 }
             }
             else
@@ -1297,7 +1327,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     return HRT_OK;
 }
 
-int build_boolean_query_tree(hrt_ctx* c, DeviceState& d);       // defined with the scene-update code below
+int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce);       // defined with the scene-update code below
 
 } // namespace
 
@@ -1575,7 +1605,7 @@ try {
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
-        if (int rcB = build_boolean_query_tree(c, d)) return rcB;
+        if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once)) return rcB;
     }
     c->scene_ready = true;
     return HRT_OK;
@@ -1609,19 +1639,21 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 }
 
 // Scenes made of many fast-sphere instances (identity transform, one sphere): a second TLAS over the same instances, built on
-// the device with the LBVH of the scene updates, for the queries whose answer does not depend on the tree -- any-hit walks and
-// the last bounce's hit-or-miss walk (hrt_walker.hpp, ALT).  The reference's median split cuts such a scene into slabs when one
-// instance dominates the bounds (the ground sphere of BASELINE config 3: 103 node visits per ray against 50); the
-// closest-hit walks of the other bounces keep the uploaded tree, whose order decides ties.  Dropped again by the first scene
-// update (the tree in use is then device-built anyway, or its boxes have moved).
+// the device with the LBVH of the scene updates, for the walks of the streamed pipeline (hrt_walker.hpp, ALT).  Any-hit walks and
+// the last bounce's hit-or-miss walk do not depend on the tree at all; a closest-hit walk depends on it only through the order
+// in which instances at exactly the same distance are met, which the walker detects and resolves on the uploaded tree.  The
+// reference's median split cuts such a scene into slabs when one instance dominates the bounds (the ground sphere of BASELINE
+// config 3: 103 node visits per ray against 50).  Needs the uploaded tree to list every instance exactly once (the
+// second tree is built over "the instances").  Dropped again by the first scene update (the tree in use is then device-built
+// anyway, or its boxes have moved).
 constexpr int64_t kAnyTreeMinInstances = 256;
-int build_boolean_query_tree(hrt_ctx* c, DeviceState& d)
+int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce)
 {
     d.any_ok = false;
 #ifdef HRT_NO_ANY_TREE             // A/B
     return HRT_OK;
 #endif
-    if (!c->packed_ok || c->packed_feat != 0 || c->n_inst < kAnyTreeMinInstances || !d.dpacked.tlasX) return HRT_OK;
+    if (!c->packed_ok || c->packed_feat != 0 || c->n_inst < kAnyTreeMinInstances || !d.dpacked.tlasX || !instOnce || nSlots != c->n_inst) return HRT_OK;
     int rc = ensure_lbvh_scratch(c, d);
     if (rc != HRT_OK) return rc;
     TlasDevice T = d.tl;                                        // inputs, capacities, temporaries and LBVH scratch are shared; outputs are its own
@@ -1646,10 +1678,25 @@ int build_boolean_query_tree(hrt_ctx* c, DeviceState& d)
     HIPCHK(c, hipMemcpyAsync(flags, T.flags, sizeof(flags), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(c, hipStreamSynchronize(d.stream));
     if (flags[0] != 0 || leaves <= 0 || (int64_t)T.nT + T.nTI >= kEnd) return HRT_OK;      // an instance that is not a fast sphere after all
+    // leaf slot of the uploaded tree -> leaf slot of this one (both list every instance once)
+    if (T.nTI != (int)nSlots) return HRT_OK;
+    std::vector<int32_t> mine((size_t)nSlots), slotOfInst((size_t)c->n_inst, -1), map((size_t)nSlots);
+    HIPCHK(c, hipMemcpyAsync(mine.data(), T.tlasInst, (size_t)nSlots * 4, hipMemcpyDeviceToHost, d.stream));
+    HIPCHK(c, hipStreamSynchronize(d.stream));
+    for (int64_t a = 0; a < nSlots; a++)
+    {
+        if (mine[(size_t)a] < 0 || mine[(size_t)a] >= c->n_inst || slotOfInst[(size_t)mine[(size_t)a]] >= 0) return HRT_OK;
+        slotOfInst[(size_t)mine[(size_t)a]] = (int32_t)a;
+    }
+    for (int64_t o = 0; o < nSlots; o++) map[(size_t)o] = slotOfInst[(size_t)uploadedSlots[o]];
+    if (d.tl2mem[14]) { (void)hipFree(d.tl2mem[14]); d.tl2mem[14] = nullptr; }
+    HIPCHK(c, hipMalloc(&d.tl2mem[14], (size_t)nSlots * 4));
+    HIPCHK(c, hipMemcpy(d.tl2mem[14], map.data(), (size_t)nSlots * 4, hipMemcpyHostToDevice));
     d.tl2 = T;
     d.dpackedAny = d.dpacked;
     d.dpackedAny.tlas = T.tlas; d.dpackedAny.finst = T.finst; d.dpackedAny.nTlas = T.nT;
     d.dpackedAny.tlasX = T.tlasX; d.dpackedAny.nTlasX = T.nT + T.nTI;
+    d.dpackedAny.slotMap = (const int*)d.tl2mem[14];
     d.any_ok = true;
     return HRT_OK;
 }

@@ -54,6 +54,7 @@ struct DPacked {
     int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
     const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
+    const int* slotMap;      // second tree over the same instances (hrt_walker.hpp, ALT): leaf slot of the uploaded tree -> leaf slot here; else nullptr
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514

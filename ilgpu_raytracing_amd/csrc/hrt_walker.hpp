@@ -60,11 +60,18 @@ __device__ unsigned long long g_walk_stats[2][24];
 // are fixed, every box above it contains it exactly, and enlarging a box can only turn a miss into a hit: DESIGN.md 4), so the
 // tree above the instances decides nothing.  The argument needs finite slab arithmetic: a ray with a non-finite origin or 1/d
 // walks the uploaded tree (`exact`) when it is fetched.
+// ALT on a closest-hit walk that is not EXISTS: the winner is the accepted hit of least t over the instances whose own box test
+// passes (same argument: the boxes above only prune what cannot win, t < bestT being strict and the box tests inclusive), and the
+// tree only decides WHICH of several instances with exactly the same t wins (the first in the uploaded tree's order).  The walk
+// therefore notes when a candidate equals the current best (a tie is never pruned: its boxes are entered at or before t), and
+// such a ray -- none in practice -- walks the uploaded tree at retirement.  Results carry leaf slots of `tr`'s tree
+// (DPacked::slotMap translates the uploaded tree's), so the shading that follows reads `tr`'s instance records.
 template <int FEAT, bool ANY, bool COUNT, bool EXISTS, bool ALT, class NextSeg, class Fetch, class Done>
 HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
     static_assert(!(EXISTS && (ANY || COUNT)), "EXISTS is a closest-hit walk of a production frame");
-    static_assert(!ALT || ((ANY || EXISTS) && !COUNT && FEAT == 0), "another tree only for boolean queries over fast-sphere instances");
+    static_assert(!ALT || (!COUNT && FEAT == 0), "another tree only for production frames of fast-sphere instances");
+    constexpr bool kTies = ALT && !ANY && !EXISTS;          // closest-hit walk over the other tree: watch for equal-t candidates
     constexpr bool kGeneral = (FEAT & 1) != 0;
     constexpr bool kAlpha = (FEAT & 2) != 0;
     // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
@@ -89,7 +96,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
     w.o = w.d = w.inv = mk3(0.f, 0.f, 0.f);
     float tMaxW = 0.f;               // ANY: world tMax
     float bestT = 1e30f, bestTObj = 0.f; int bestSlot = -1, bestPrim = -1;     // closest
-    bool occl = false;
+    bool occl = false, tie = false;
     int cur = 0, li = 0, lend = 0, lskip = kEnd;          // TLAS walk / leaf iteration
     int bj = 0, bend = 0, bskip = kEnd;                   // BLAS leaf iteration
     int blasEnd = 0, iflags = 0, islot = 0; float iscale = 1.f, tObj = 1e30f; int iprim = -1;   // instance being walked
@@ -118,16 +125,12 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                     if (mode == M_IDLE && rank < avail)
                     {
                         rayIdx = segBase + segCur + rank;
-                        bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false;
+                        bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false; tie = false;
                         if (fetch(rayIdx, w, tMaxW))
                         {
                             C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS;
-                            if (ALT && !finite_ray(w))
-                            {   // the tree-independence argument needs finite slab arithmetic: this ray walks the uploaded tree, now
-                                if (ANY) occl = exact.template occluded_ext<COUNT, true>(w, tMaxW, C, park_mem);
-                                else exact.template closest_raw<COUNT, true>(w, bestT, bestTObj, bestSlot, bestPrim, C, park_mem);
-                                mode = M_DONE;
-                            }
+                            // the tree-independence argument needs finite slab arithmetic: this ray walks the uploaded tree (at retirement)
+                            if (ALT && !finite_ray(w)) { tie = true; mode = M_DONE; }
                         }
                         else mode = M_DONE;                   // queue entry without a ray (path already ended)
                     }
@@ -222,6 +225,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
             {
                 if (ANY) { occl = true; mode = M_DONE; }
                 else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); if (EXISTS) mode = M_DONE; }
+                else if (kTies && t == bestT) tie = true;
             }
             if (mode == M_TLEAF) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
         }
@@ -242,6 +246,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                     {
                         if (ANY) { occl = true; mode = M_DONE; }
                         else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); if (EXISTS) mode = M_DONE; }
+                        else if (kTies && t == bestT) tie = true;
                     }
                 }
                 li++;
@@ -359,6 +364,17 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
 #endif
         if (mode == M_DONE)
         {
+            if (ALT && tie)
+            {   // a non-finite ray, or (kTies) two instances at exactly the same distance: the uploaded tree decides
+                tie = false;
+                if (ANY) occl = exact.template occluded_ext<COUNT, true>(w, tMaxW, C, park_mem);
+                else
+                {
+                    bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1;
+                    exact.template closest_raw<COUNT, true>(w, bestT, bestTObj, bestSlot, bestPrim, C, park_mem);
+                    if (kTies && bestSlot >= 0) bestSlot = P.slotMap[bestSlot];
+                }
+            }
             WalkResult r; r.t = bestT; r.tObj = bestTObj; r.slot = bestSlot; r.prim = bestPrim; r.occluded = occl;
             done(rayIdx, r);
             mode = M_IDLE;

@@ -75,3 +75,42 @@ def test_boolean_queries_on_the_second_tree_change_nothing(orc, hrt_lib):
         H.assert_outputs_equal(ref, again)
     finally:
         r.close()
+
+
+def test_equal_distance_instances_on_the_second_tree(orc, hrt_lib):
+    """Closest-hit walks over the second tree must still name the instance the UPLOADED tree meets first when several lie at exactly
+    the same distance (hrt_walker.hpp, kTies).  400 fast-sphere instances of which 120 are exact duplicates (same centre and radius)
+    of others with another colour or shading -- every ray that hits one ties -- listed before or after their twins."""
+    def build(b):
+        rng = scenes.XorShift32(0xFACEFEED)
+        recs = [((0.0, -1000.0, 0.0), 1000.0, (0.6, 0.6, 0.6), T.SHADING_LAMBERT, 1.0)]
+        for i in range(280):
+            c = (rng.uniform(-5, 5), rng.uniform(0.1, 2.5), rng.uniform(-5, 5))
+            recs.append((c, rng.uniform(0.1, 0.4), (rng.uniform(0.2, 0.9), rng.uniform(0.2, 0.9), rng.uniform(0.2, 0.9)), T.SHADING_LAMBERT, 1.0))
+        twins = []
+        for j in range(120):
+            c, rad, kd, _, _ = recs[1 + 2 * j]
+            kind = j % 3
+            twins.append((c, rad, (1.0 - kd[0], 1.0 - kd[1], kd[2]), [T.SHADING_LAMBERT, T.SHADING_MIRROR, T.SHADING_GLASS][kind], 1.5))
+        order = recs[:1] + twins[:60] + recs[1:] + twins[60:]        # half of the twins come first in the instance list, half last
+        ids = [b.add_sphere(scenes.sphere(c, rad, kd, sh, ior)) for c, rad, kd, sh, ior in order]
+        for i in ids:
+            b.build_sphere_instance([i])
+        b.rebuild_tlas()
+    cfg = scenes.Config("ties", 0, 0, 0, (0.0, 3.0, 9.0), (0.0, 0.8, 0.0), max_depth=4)
+    w, h, spp = 224, 128, 3
+    ref, ost, _ = H.oracle_frame(orc, build, cfg, w, h, spp)
+    r = engine.RTRenderer([0])
+    try:
+        s = engine.Scene(); build(s); r.commit(s)
+        p = _params(cfg, w, h, spp)
+        prod, op = T.alloc_outputs(w, h)
+        r.render_params(p, op, flags=T.FLAG_STREAMED)
+        H.assert_outputs_equal(ref, prod)
+        r.reset_history()
+        cnt, oc = T.alloc_outputs(w, h)
+        st = r.render_params(p, oc, flags=T.FLAG_STREAMED | T.FLAG_COUNTERS)
+        H.assert_outputs_equal(ref, cnt)
+        assert st.k[1].as_dict() == ost.k[1].as_dict()
+    finally:
+        r.close()
