@@ -2105,8 +2105,18 @@ try {
             const dim3 grid(tm.nTiles), block(64 * tm.wpb);
             int rcs = with_tracer(d, [&](auto tr) -> int {
                 using TR = decltype(tr);
-                if (count) hipLaunchKernelGGL((hrt_primary_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
-                else       hipLaunchKernelGGL((hrt_primary_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
+                bool second = false;
+                if constexpr (std::is_same<TR, TracerPackedT<0>>::value) second = !count && d.any_ok;
+                if (second)
+                {
+                    if constexpr (std::is_same<TR, TracerPackedT<0>>::value)
+                    {
+                        TracerSecond t2; t2.second = tr; t2.second.P = d.dpackedAny; t2.uploaded = tr;
+                        hipLaunchKernelGGL((hrt_primary_kernel<TracerSecond, false>), grid, block, 0, d.stream, t2, k, d.gb, tm, d.counters);
+                    }
+                }
+                else if (count) hipLaunchKernelGGL((hrt_primary_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
+                else            hipLaunchKernelGGL((hrt_primary_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, tm, d.counters);
                 HIPCHK(c, hipGetLastError());
                 return HRT_OK;
             });

@@ -253,8 +253,10 @@ struct TracerPackedT {
     }
     // the walk alone: raw winner (world t, object-space t, TLAS leaf slot, primitive), t = 1e30 on a miss
     // EXT: the caller lends its own LDS ray park (kernels that already have one must not pay for a second)
-    template <bool COUNT, bool EXT = false>
-    HRT_D void closest_raw(const Ray& wray_in, float& bestT, float& bestTObj, int& bestSlot, int& bestPrim, Cnt<COUNT>& C, float (*ext)[256] = nullptr) const
+    // TIES: *tie is set when a fast-sphere candidate lies at exactly the current best distance (TracerSecond below)
+    template <bool COUNT, bool EXT = false, bool TIES = false>
+    HRT_D void closest_raw(const Ray& wray_in, float& bestT, float& bestTObj, int& bestSlot, int& bestPrim, Cnt<COUNT>& C, float (*ext)[256] = nullptr,
+                           bool* tie = nullptr) const
     {
         RayPark park;
         if constexpr (EXT) park.sh = ext;
@@ -297,6 +299,7 @@ struct TracerPackedT {
                         {
                             // hit = tClosest < 1e29 (:169); tWorld = t / 1 (:67)
                             if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = i; bestPrim = wbits(f.b); }
+                            else if (TIES && t == bestT) *tie = true;
                         }
                     }
                 }
@@ -549,6 +552,27 @@ using TracerPacked = TracerPackedT<3>;       // everything compiled in
 // not produced here: counting frames use TracerPackedT<0>.
 // ---------------------------------------------------------------------------------------
 constexpr int kFlatMaxLeaves = 16;
+// One-ray-per-lane closest hit of a fast-sphere scene over the SECOND tree (DPacked::slotMap, hrt_walker.hpp ALT): the winner is
+// the accepted hit of least t whatever the tree; a ray that met two instances at exactly the same distance, or whose slab
+// arithmetic is not finite, walks the uploaded tree instead.  Leaf slots handed to finish_hit are the second tree's.
+struct TracerSecond {
+    TracerPackedT<0> second, uploaded;
+    template <bool COUNT>
+    HRT_D bool closest(const Ray& wray, Hit& best, Cnt<COUNT>& C) const
+    {
+        static_assert(!COUNT, "work counters are defined on the uploaded tree");
+        float t = 1e30f, tObj = 0.f; int slot = -1, prim = -1;
+        bool tie = !finite_ray(wray);
+        if (!tie) second.template closest_raw<COUNT, false, true>(wray, t, tObj, slot, prim, C, nullptr, &tie);
+        if (tie)
+        {
+            uploaded.template closest_raw<COUNT>(wray, t, tObj, slot, prim, C);
+            if (slot >= 0) slot = second.P.slotMap[slot];
+        }
+        return second.finish_hit(wray, t, tObj, slot, prim, best);
+    }
+};
+
 // Wave-uniform records through the SCALAR cache: a pointer in the constant address space makes the compiler fetch with s_load
 // into scalar registers (one request per wave, ~4x shorter latency than the vector path, no vector registers) instead of a
 // 64-lane global_load of one address.  Valid here because the scene arrays are never written while a render kernel runs.
