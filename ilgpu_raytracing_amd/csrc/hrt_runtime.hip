@@ -1674,6 +1674,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     HIPCHK(c, tlas_rebuild_topology(T, d.stream, &leaves));
     T.directMax = 63;                                           // emitted in walk order
     HIPCHK(c, tlas_finish(T, d.stream));
+    HIPCHK(c, tlas_inflate(T, d.stream));
     int flags[4] = {1, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(flags, T.flags, sizeof(flags), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(c, hipStreamSynchronize(d.stream));

@@ -73,6 +73,36 @@ HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)  
     tmax = hrt_fmin(tmax, hrt_fmax(t1, t2));
     return tmax >= hrt_fmax(tmin, tMin) && tmin <= tMax;
 }
+// tmin of the test above (the slab entry distance as IntersectAABB computes it)
+HRT_D float box_entry(const Ray& r, float4 lo, float4 hi)
+{
+    float t1 = (lo.x - r.o.x) * r.inv.x;
+    float t2 = (hi.x - r.o.x) * r.inv.x;
+    float tmin = hrt_fmin(t1, t2);
+    t1 = (lo.y - r.o.y) * r.inv.y;
+    t2 = (hi.y - r.o.y) * r.inv.y;
+    tmin = hrt_fmax(tmin, hrt_fmin(t1, t2));
+    t1 = (lo.z - r.o.z) * r.inv.z;
+    t2 = (hi.z - r.o.z) * r.inv.z;
+    return hrt_fmax(tmin, hrt_fmin(t1, t2));
+}
+// Closest-hit walks over the SECOND tree of a fast-sphere scene (DPacked::slotMap; hrt_walker.hpp kTies, TracerSecond below).
+// What the reference computes is, with one exception, the accepted hit of least t over the instances whose own box test (limit
+// 1e30) passes, ties going to the first in its walk order:
+//   (R) an instance w whose own slab entry is <= its hit distance (tmin_w <= t_w) is never pruned by the reference while it
+//       could still win: every box above it contains its own, so their entries are <= tmin_w <= t_w <= the closest t so far.
+// The exception is a winner whose computed entry EXCEEDS its computed hit distance (rounding: the float box can be a fraction of
+// an ulp smaller than the sphere, and t of a grazing hit carries an absolute error of ~7e-4 of the distance), which a node test
+// with a closest t between the two can skip or not, depending on the order.  So:
+//   (1) the second tree's node boxes are inflated (hrt_bvh.hip, tlas_inflate) and its node tests take closest * kSecondLimit, so
+//       that no instance with t_i < closest is pruned even when its entry exceeds t_i by the bound below -- the walk finds the
+//       least t over ALL candidates;
+//   (2) a candidate at exactly the closest t so far (a tie), or a winner with tmin_w > t_w, sends the ray to the uploaded tree.
+// Bound used by (1), for a candidate of radius r at centre c hit at t: tmin - t <= 2^-8 t + 4 sqrt(2 r 2^-24 (|c|+r)) + 2^-7 r
+// (cap of the sphere outside its rounded box: chord 2 sqrt(2 r beta), beta = half an ulp of |c| + r; square-root amplification
+// of the discriminant's rounding at grazing incidence: sqrt(8 2^-24) (1.5 |o - c| + r) with |o - c| <= t + r; both doubled).
+constexpr float kSecondLimit = 1.f + 0x1p-7f;
+
 // The world ray is dead weight while a general instance's BLAS is walked with the object-space
 // ray, but it must survive for the rest of the TLAS walk.  hipcc can only spill to scratch
 // (global memory, hundreds of cycles inside a latency-bound loop); parking the 9 floats in LDS
@@ -267,6 +297,7 @@ struct TracerPackedT {
         bestTObj = 0.f;             // object-space t of the winner (== bestT * scale)
         bestSlot = -1;              // TLAS leaf slot (index into finst / tlasInstanceIndices)
         bestPrim = -1;              // sphere index, or BLAS leaf slot of the triangle
+        bool anom = false;          // TIES: the current winner's own slab entry exceeds its hit distance
         int cur = 0;
         for (;;)
         {
@@ -278,11 +309,11 @@ struct TracerPackedT {
                 int sk = wbits(n.hi);
                 int cnt = (int)((unsigned)sk >> 28);
                 sk &= kEnd;
-                if (!hit_box(wray, n.lo, n.hi, 0.001f, bestT)) { cur = sk; continue; }
+                if (!hit_box(wray, n.lo, n.hi, 0.001f, TIES ? bestT * kSecondLimit : bestT)) { cur = sk; continue; }
                 if (cnt > 0) { lfirst = wbits(n.lo); lcount = cnt; lskip = sk; break; }
                 cur = wbits(n.lo) & kEnd;
             }
-            if (lcount == 0) return;
+            if (lcount == 0) { if (TIES && anom) *tie = true; return; }
             for (int i = lfirst; i < lfirst + lcount; i++)
             {
                 FInst f = P.finst[i];
@@ -298,7 +329,11 @@ struct TracerPackedT {
                         if (hit_sphere_t(wray, xyz(f.c), f.c.w, t) && t > 0.001f && t < 1e30f)
                         {
                             // hit = tClosest < 1e29 (:169); tWorld = t / 1 (:67)
-                            if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = i; bestPrim = wbits(f.b); }
+                            if (t < 1e29f && t < bestT)
+                            {
+                                bestT = t; bestTObj = t; bestSlot = i; bestPrim = wbits(f.b);
+                                if (TIES) anom = box_entry(wray, f.a, f.b) > t;
+                            }
                             else if (TIES && t == bestT) *tie = true;
                         }
                     }

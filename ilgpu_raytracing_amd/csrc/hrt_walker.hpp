@@ -60,12 +60,11 @@ __device__ unsigned long long g_walk_stats[2][24];
 // are fixed, every box above it contains it exactly, and enlarging a box can only turn a miss into a hit: DESIGN.md 4), so the
 // tree above the instances decides nothing.  The argument needs finite slab arithmetic: a ray with a non-finite origin or 1/d
 // walks the uploaded tree (`exact`) when it is fetched.
-// ALT on a closest-hit walk that is not EXISTS: the winner is the accepted hit of least t over the instances whose own box test
-// passes (same argument: the boxes above only prune what cannot win, t < bestT being strict and the box tests inclusive), and the
-// tree only decides WHICH of several instances with exactly the same t wins (the first in the uploaded tree's order).  The walk
-// therefore notes when a candidate equals the current best (a tie is never pruned: its boxes are entered at or before t), and
-// such a ray -- none in practice -- walks the uploaded tree at retirement.  Results carry leaf slots of `tr`'s tree
-// (DPacked::slotMap translates the uploaded tree's), so the shading that follows reads `tr`'s instance records.
+// ALT on a closest-hit walk that is not EXISTS (kTies): see "Closest-hit walks over the SECOND tree" in hrt_trace_packed.hpp --
+// node tests take closest * kSecondLimit over inflated boxes, so the walk finds the least t over all candidates; a candidate at
+// exactly the closest t so far, or a winner whose own slab entry exceeds its hit distance, sends the ray to the uploaded tree at
+// retirement (none in practice).  Results carry leaf slots of `tr`'s tree (DPacked::slotMap translates the uploaded tree's), so
+// the shading that follows reads `tr`'s instance records.
 template <int FEAT, bool ANY, bool COUNT, bool EXISTS, bool ALT, class NextSeg, class Fetch, class Done>
 HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
@@ -96,7 +95,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
     w.o = w.d = w.inv = mk3(0.f, 0.f, 0.f);
     float tMaxW = 0.f;               // ANY: world tMax
     float bestT = 1e30f, bestTObj = 0.f; int bestSlot = -1, bestPrim = -1;     // closest
-    bool occl = false, tie = false;
+    bool occl = false, tie = false, anom = false;
     int cur = 0, li = 0, lend = 0, lskip = kEnd;          // TLAS walk / leaf iteration
     int bj = 0, bend = 0, bskip = kEnd;                   // BLAS leaf iteration
     int blasEnd = 0, iflags = 0, islot = 0; float iscale = 1.f, tObj = 1e30f; int iprim = -1;   // instance being walked
@@ -125,7 +124,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                     if (mode == M_IDLE && rank < avail)
                     {
                         rayIdx = segBase + segCur + rank;
-                        bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false; tie = false;
+                        bestT = 1e30f; bestTObj = 0.f; bestSlot = -1; bestPrim = -1; occl = false; tie = false; anom = false;
                         if (fetch(rayIdx, w, tMaxW))
                         {
                             C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS;
@@ -163,7 +162,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
 #pragma unroll
                 for (int k = 0; k < kLook; k++) nds[k] = nodes[cur + k <= last ? cur + k : last];
                 __builtin_amdgcn_sched_barrier(0);           // all loads leave before the first box test waits on one of them
-                const float lim = top ? (ANY ? tMaxW : bestT) : (ANY ? tMaxW * iscale : tObj);
+                const float lim = top ? (ANY ? tMaxW : (kTies ? bestT * kSecondLimit : bestT)) : (ANY ? tMaxW * iscale : tObj);
 #pragma unroll
                 for (int k = 0; k < kLook; k++)
                 {
@@ -224,7 +223,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
             if (hit_sphere_t(w, xyz(fc), fc.w, t) && t > 0.001f && t < lim)
             {
                 if (ANY) { occl = true; mode = M_DONE; }
-                else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); if (EXISTS) mode = M_DONE; }
+                else if (t < 1e29f && t < bestT)
+                {
+                    bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(fb); if (EXISTS) mode = M_DONE;
+                    if (kTies) anom = box_entry(w, P.finst[li].a, fb) > t;
+                }
                 else if (kTies && t == bestT) tie = true;
             }
             if (mode == M_TLEAF) { cur = lskip; mode = (cur == kEnd) ? M_DONE : M_TLAS; }
@@ -245,7 +248,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                     if (hit_sphere_t(w, xyz(f.c), f.c.w, t) && t > 0.001f && t < lim)
                     {
                         if (ANY) { occl = true; mode = M_DONE; }
-                        else if (t < 1e29f && t < bestT) { bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); if (EXISTS) mode = M_DONE; }
+                        else if (t < 1e29f && t < bestT)
+                        {
+                            bestT = t; bestTObj = t; bestSlot = li; bestPrim = wbits(f.b); if (EXISTS) mode = M_DONE;
+                            if (kTies) anom = box_entry(w, f.a, f.b) > t;
+                        }
                         else if (kTies && t == bestT) tie = true;
                     }
                 }
@@ -364,6 +371,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
 #endif
         if (mode == M_DONE)
         {
+            if (kTies && anom) tie = true;
             if (ALT && tie)
             {   // a non-finite ray, or (kTies) two instances at exactly the same distance: the uploaded tree decides
                 tie = false;
