@@ -195,6 +195,27 @@ def measure_pmc(cfg_id, spp, out_dir, timeout_s=240):
     return {"frames": frames, "kernels": kernels}
 
 
+def is_counting_kernel(name):
+    """True for the work-counter instantiation of a kernel (its frames are not the timed ones).  COUNT is the first template argument
+    of hrt_wf_shade_kernel and the second of every other kernel of the path-trace stage."""
+    lt = name.find("<")
+    if lt < 0:
+        return False
+    args, depth, cur = [], 0, ""
+    for ch in name[lt + 1:name.rfind(">")]:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    args.append(cur.strip())
+    pos = 0 if name.startswith("hrt_wf_shade_kernel") else 1
+    return len(args) > pos and args[pos] == "true"
+
+
 def pmc_for(cfg_id, spp, allow_run, out_dir):
     """(per-launch counter sums of the path-trace stage, source description).  Measured now if allowed, else the committed file."""
     src = None
@@ -218,7 +239,7 @@ def pmc_for(cfg_id, spp, allow_run, out_dir):
     stage = {}
     names = []
     for k, cs in res["kernels"].items():
-        if "primary" in k or "true>" in k:
+        if "primary" in k or is_counting_kernel(k):
             continue
         names.append(k)
         for c, v in cs.items():

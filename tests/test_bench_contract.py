@@ -47,3 +47,17 @@ def test_bench_refuses_to_run_without_a_gpu():
         pytest.skip("GPU present")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode != 0 and "no CPU path" in (out.stderr + out.stdout)
+
+
+def test_counting_kernels_are_told_from_production_ones_by_their_count_argument():
+    """bench.py prices the PMC counters of the production kernels only.  COUNT is the first template argument of the shade kernel
+    and the second of every other one; a trailing `true>` may be EXISTS or ALT."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cases = {"hrt_wf_walk_closest_kernel<0, false, false, true>": False, "hrt_wf_walk_closest_kernel<0, false, true, true>": False,
+             "hrt_wf_walk_shadow_kernel<0, false, true>": False, "hrt_wf_walk_shadow_kernel<0, true, false>": True,
+             "hrt_wf_shade_kernel<true, false>": True, "hrt_wf_shade_kernel<false, true>": False, "hrt_wf_finish_kernel<1, false>": False,
+             "hrt_path_trace_kernel<hrt::TracerPackedT<0>, true>": True, "hrt_path_trace_kernel<hrt::TracerFlat, false>": False,
+             "hrt_wf_resolve_kernel": False}
+    for name, want in cases.items():
+        assert bench.is_counting_kernel(name) == want, name
