@@ -273,6 +273,12 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
                         sadd = T * (f_over_p * Wt);          // added to Li by wf_shadow iff unoccluded (:286/:291)
                     }
                 }
+                // The reference adds T * contrib also when contrib is (0, 0, 0) -- no light selected, or occluded (:286/:291).  That is a
+                // no-op (Li is never -0) unless a component of T is not finite (albedo products that overflowed): inf * 0 = NaN, and the
+                // component stays non-finite to the end of the sample, where SafeColor zeroes it, whatever else is added -- so it is
+                // poisoned here, before the visibility is known.  (T = 1 at a sample's first vertex.)
+                if (!FIRST && !(hrt_isfinite(T.x) && hrt_isfinite(T.y) && hrt_isfinite(T.z)))
+                    V.st3(V_LI, slot, V.ld3(V_LI, slot) + T * mk3(0.f, 0.f, 0.f));
                 if (!(flg & RF_WROTE))
                 {   // first diffuse vertex of this sample: stage the reservoir (resCur.Write :292-296)
                     W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, res_pdf(nrm, r));

@@ -337,3 +337,26 @@ def test_full_size_config3_strip(orc, renderer):
     ref, ost, _ = H.oracle_frame(orc, scenes.build_config3, cfg, w, h, 4, rows=rows)
     H.assert_outputs_equal(ref, got, names=names, rows=rows, width=w)
     assert st.k[1].as_dict() == ost.k[1].as_dict()
+
+
+def _overflow_scene(b):
+    """Albedos of 2e19 .. 4e19: the throughput of a second diffuse bounce overflows to +inf, and the reference's Li += T * contrib with
+    contrib = (0, 0, 0) (nothing selected, or occluded) then makes the component NaN -> SafeColor zeroes it (RTRay.cs:286-291, 646-655)."""
+    ids = [b.add_sphere(scenes.sphere((0.0, -1000.0, 0.0), 1000.0, (3e19, 3e19, 1.0)))]
+    rng = scenes.XorShift32(77)
+    for i in range(30):
+        c = (rng.uniform(-3, 3), rng.uniform(0.2, 1.5), rng.uniform(-3, 3))
+        kd = (2e19, 0.5, 4e19) if i % 3 == 0 else (0.7, 0.6, 0.5)
+        ids.append(b.add_sphere(scenes.sphere(c, rng.uniform(0.2, 0.5), kd, T.SHADING_MIRROR if i % 5 == 0 else T.SHADING_LAMBERT)))
+    for i in ids:
+        b.build_sphere_instance([i])
+    b.rebuild_tlas()
+
+
+@pytest.mark.parametrize("flags", [T.FLAG_MEGAKERNEL, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS, T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT])
+def test_overflowing_throughput(orc, renderer, flags):
+    cfg = scenes.Config("ovf", 0, 0, 0, (0.0, 2.5, 7.0), (0.0, 0.6, 0.0), max_depth=5)
+    ref, _, _ = H.oracle_frame(orc, _overflow_scene, cfg, 160, 96, 3)
+    assert int(np.count_nonzero(ref["radiance"].sum(axis=1) == 0)) > 0          # the case occurs
+    got, _, _ = _gpu_frame(renderer, _overflow_scene, cfg, 160, 96, 3, flags=flags)
+    H.assert_outputs_equal(ref, got)
