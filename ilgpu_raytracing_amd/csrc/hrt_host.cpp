@@ -370,12 +370,20 @@ struct HostScene {
         std::vector<int> val(nTris);
         V3 mbmin = v3(FLT_MAX, FLT_MAX, FLT_MAX), mbmax = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
         for (int i = 0; i < nTris; i++) {
-            const hrt_mesh_tri& t = meshTris[baseTri + i];
+            // BuildBLAS_Triangles hands the recursion idx[i] = baseTri + i and the recursion reads primIdx[idx[i]] (Scene.cs:398-403,
+            // :428): the triangle list is looked up BY POSITION in the prim-index list, which holds this mesh's own triangles at
+            // [baseTri, baseTri + n) only for the first mesh of a scene -- every earlier mesh has appended its leaf copies in between.
+            // The BLAS of a later mesh is therefore built over whatever triangles that window names (entries below the list's
+            // length at this point never change afterwards).  Restated literally; the instance bounds below are the mesh's own.
+            const int triIndex = triPrimIdx[(size_t)baseTri + (size_t)i];
+            const hrt_mesh_tri& t = meshTris[(size_t)triIndex];
             V3 a = v3(meshPositions[t.i0]), b = v3(meshPositions[t.i1]), c = v3(meshPositions[t.i2]);
             lmin[i] = vmin(a, vmin(b, c)); lmax[i] = vmax(a, vmax(b, c));
             key[0][i] = (a.x + b.x + c.x) / 3.f; key[1][i] = (a.y + b.y + c.y) / 3.f; key[2][i] = (a.z + b.z + c.z) / 3.f;
-            val[i] = baseTri + i;
-            mbmin = vmin(mbmin, lmin[i]); mbmax = vmax(mbmax, lmax[i]);      // ComputeMeshBounds :582-595
+            val[i] = triIndex;
+            const hrt_mesh_tri& own = meshTris[(size_t)baseTri + (size_t)i];                  // ComputeMeshBounds :582-595 (mesh.Positions / mesh.Triangles)
+            mbmin = vmin(mbmin, vmin(v3(meshPositions[own.i0]), vmin(v3(meshPositions[own.i1]), v3(meshPositions[own.i2]))));
+            mbmax = vmax(mbmax, vmax(v3(meshPositions[own.i0]), vmax(v3(meshPositions[own.i1]), v3(meshPositions[own.i2]))));
         }
         int blasStart = (int)blasNodes.size();
         build_blas(nTris, lmin, lmax, key, val, /*byPosition=*/false, triPrimIdx);

@@ -62,7 +62,9 @@ def normalize(v):                                               # Float3.cs:94-9
 def f3(rec): return (f32(rec["X"]), f32(rec["Y"]), f32(rec["Z"]))
 
 
-def trunc_int(x):                                               # C# (int)float: toward zero
+def trunc_int(x):                                               # C# (int)float: toward zero; NaN and out-of-range as include/hrt_math.h hrt_f2i
+    if not (x >= -2147483648.0 and x < 2147483648.0):
+        return -2147483648
     return int(x)
 
 

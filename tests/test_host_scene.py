@@ -67,6 +67,29 @@ def test_many_tied_centroids(orc, hrt_lib):
     _same_arrays(a, b)
 
 
+def test_several_meshes_position_indexed_quirk(orc, hrt_lib):
+    """BuildBLAS_Triangles looks the triangles of a mesh up BY POSITION in the prim-index list (Scene.cs:398-403, :428), where the
+    leaf copies of every earlier mesh sit in between: the BLAS of the second, third, ... mesh of a scene is built over the triangles
+    that window happens to name, not its own.  Both builders restate that literally; the known answer below pins which triangles
+    those are for three 2x2-quad meshes (8 triangles each)."""
+    def build(b):
+        s = np.linspace(-1.0, 1.0, 3)
+        yq, xq = np.meshgrid(s, s, indexing="ij")
+        for k in range(3):
+            b.load_mesh_instance(scenes.grid_mesh(xq + 3.0 * k, yq, 0.1 * xq * yq - k, (xq + 1) / 2, (yq + 1) / 2))
+    a, b = orc.OrcScene(), engine.Scene()
+    build(a); build(b)
+    A = _same_arrays(a, b)
+    prim = [int(v) for v in A["triPrimIdx"]]
+    assert len(prim) == 3 * 16                               # per mesh: 8 identity entries, then 8 leaf copies
+    assert prim[0:8] == list(range(8)) and prim[16:24] == list(range(8, 16)) and prim[32:40] == list(range(16, 24))
+    assert sorted(prim[8:16]) == list(range(8))              # mesh 0: its own triangles
+    assert sorted(prim[24:32]) == list(range(8))             # mesh 1: window [8, 16) of the list = mesh 0's leaf copies
+    assert sorted(prim[40:48]) == list(range(8, 16))         # mesh 2: window [16, 24) = mesh 1's identity entries
+    inst = A["instances"]
+    assert [int(r["primIndexFirst"]) for r in inst] == [0, 8, 16]
+
+
 def test_empty_scene(orc, hrt_lib):
     a, b = orc.OrcScene(), engine.Scene()
     a.rebuild_tlas(); b.rebuild_tlas()

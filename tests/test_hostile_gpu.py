@@ -1,0 +1,141 @@
+"""Inputs nobody would author on purpose: degenerate primitives, non-finite numbers in the scene and in the frame parameters,
+limits of the sample loop.  The reference computes SOMETHING for each of them (IEEE arithmetic has no exceptions), and the HIP path
+has to compute the same bits in every kernel organisation."""
+import math
+import numpy as np
+import pytest
+
+from ilgpu_raytracing_amd import _types as T, scenes, engine
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+NAN, INF = float("nan"), float("inf")
+
+
+def _spheres(recs):
+    def build(b):
+        ids = [b.add_sphere(scenes.sphere(c, r, kd, sh, ior)) for c, r, kd, sh, ior in recs]
+        for i in ids:
+            b.build_sphere_instance([i])
+        b.rebuild_tlas()
+    return build
+
+
+GROUND = ((0.0, -1000.0, 0.0), 1000.0, (0.6, 0.6, 0.6), T.SHADING_LAMBERT, 1.0)
+
+
+def _degenerate_spheres():
+    return _spheres([GROUND,
+                     ((0.0, 0.5, 0.0), 0.0, (0.9, 0.2, 0.2), T.SHADING_LAMBERT, 1.0),          # radius 0
+                     ((1.0, 0.5, 0.0), -0.4, (0.2, 0.9, 0.2), T.SHADING_LAMBERT, 1.0),         # negative radius: inverted box
+                     ((-1.0, 0.5, 0.0), 1e-30, (0.2, 0.2, 0.9), T.SHADING_MIRROR, 1.0),        # denormal-scale radius
+                     ((0.0, 1.5, 5.5), 0.8, (1.0, 1.0, 1.0), T.SHADING_GLASS, 0.0),            # the camera sits inside; ior 0 -> 1.5
+                     ((0.3, 0.4, 1.0), 0.4, (0.0, 0.0, 0.0), T.SHADING_GLASS, 1.0),            # black glass (tint 1), ior 1
+                     ((-0.6, 0.3, 1.5), 0.3, (-0.5, 2.0, 0.5), T.SHADING_LAMBERT, 1.0)])       # negative and > 1 albedo
+
+
+def _nonfinite_spheres():
+    return _spheres([GROUND,
+                     ((NAN, 0.5, 0.0), 0.4, (0.9, 0.2, 0.2), T.SHADING_LAMBERT, 1.0),
+                     ((0.8, INF, 0.0), 0.4, (0.2, 0.9, 0.2), T.SHADING_LAMBERT, 1.0),
+                     ((-0.8, 0.5, 0.0), INF, (0.2, 0.2, 0.9), T.SHADING_LAMBERT, 1.0),
+                     ((0.0, 0.5, 1.0), 0.4, (NAN, 0.5, INF), T.SHADING_LAMBERT, 1.0),
+                     ((0.9, 0.4, 1.2), 0.4, (1.0, 1.0, 1.0), T.SHADING_GLASS, NAN),
+                     ((-0.9, 0.4, 1.2), 0.4, (0.9, 0.9, 0.9), 7, 1.0)])                         # unknown shading id: Lambert branch
+
+
+def _degenerate_mesh(b):
+    scenes.build_config1(b)
+    pos = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0],          # collinear
+                    [0, 1, -1], [0, 1, -1], [0, 1, -1],        # a point
+                    [-1, 0.2, 0.5], [1, 0.2, 0.5], [0, 1.5, 0.5],   # a real one
+                    [-1, 0.2, 0.5], [1, 0.2, 0.5], [0, 1.5, 0.5],   # and its exact duplicate, other winding below
+                    [NAN, 0, 0], [1, 1, 1], [0, 1, 0]], np.float32)
+    tris = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [10, 9, 11], [12, 13, 14]], np.int32)
+    uv = np.zeros((len(pos), 2), np.float32)
+    m = scenes.material(kd=(0.8, 0.3, 0.3), two_sided=1)
+    b.load_mesh_instance(scenes.MeshData(pos, tris, uv, tris.copy(), [m], None, []))
+
+
+def _odd_transforms(b):
+    """Instance transforms Scene.InvertRigidOrUniform was never meant for: zero and negative uniform scale, a NaN entry, a huge scale."""
+    g = b.add_sphere(scenes.sphere((0.0, -300.0, 0.0), 300.0, (0.8, 0.8, 0.75)))
+    b.build_sphere_instance([g])
+    ids = [b.add_sphere(scenes.sphere((0.4 * i - 1.0, 0.3, 0.2 * (i % 3)), 0.25, (0.9 - 0.1 * i, 0.3 + 0.1 * i, 0.4))) for i in range(6)]
+    b.build_sphere_instance(ids[:2], scenes.rotation_affine("z", 15.0, 0.0, (0.5, 0.5, 0.0)))           # scale 0
+    b.build_sphere_instance(ids[2:4], scenes.rotation_affine("x", 40.0, -1.5, (-0.5, 0.8, 0.3)))       # negative scale
+    m = scenes.rotation_affine("y", 10.0, 1.0, (0.0, 1.0, 1.0)); m.m01 = NAN
+    b.build_sphere_instance(ids[4:5], m)
+    b.build_sphere_instance(ids[5:6], scenes.rotation_affine("y", 70.0, 1e20, (0.0, 0.5, -1.0)))
+    s = np.linspace(-1.0, 1.0, 4)
+    yq, xq = np.meshgrid(s, s, indexing="ij")
+    quad = scenes.grid_mesh(xq, yq, 0.1 * xq * yq, (xq + 1) / 2, (yq + 1) / 2, kd=(0.3, 0.6, 0.9))
+    b.load_mesh_instance(quad, scenes.rotation_affine("y", 35.0, -0.7, (-1.2, 1.2, -0.6)))
+    b.load_mesh_instance(quad, scenes.rotation_affine("x", 5.0, 0.0, (1.2, 1.2, -0.6)))
+
+
+def _odd_textures(b):
+    """Texture indices out of range, a 1x1 and a 1xN texture, alpha cutoff above 1 and below 0, NaN texture coordinates."""
+    tex1 = np.array([[[200, 100, 50, 255]]], np.uint8)
+    texn = np.zeros((5, 1, 4), np.uint8); texn[:, 0, 0] = [0, 60, 120, 180, 240]; texn[..., 1] = 128; texn[..., 3] = 255
+    t0, t1 = b.add_texture(tex1), b.add_texture(texn)
+    b.build_sphere_instance([b.add_sphere(scenes.sphere((0.0, -500.0, 0.0), 500.0, (1, 1, 1), mat=scenes.material(kd=(1, 1, 1), diffuse_tex=t1)))])
+    b.build_sphere_instance([b.add_sphere(scenes.sphere((-1.0, 0.5, 0.0), 0.5, (1, 1, 1), mat=scenes.material(kd=(1, 1, 1), diffuse_tex=t0)))])
+    b.build_sphere_instance([b.add_sphere(scenes.sphere((1.0, 0.5, 0.0), 0.5, (0.3, 0.9, 0.3), mat=scenes.material(kd=(0.5, 0.5, 0.5), diffuse_tex=99)))])
+    s = np.linspace(-1.0, 1.0, 5)
+    yq, xq = np.meshgrid(s * 0.7 + 0.9, s * 0.8, indexing="ij")
+    uq, vq = (xq + 0.8) / 1.6 * 3.0 - 1.0, (yq - 0.2) / 1.4 * 2.5 - 0.7                 # beyond [0, 1]: wraps
+    uq[2, 2] = NAN
+    for k, (cut, dt, at) in enumerate([(1.5, 0, 1), (-0.5, 1, 0), (0.5, 7, 1), (0.47, 1, -1)]):
+        quad = scenes.grid_mesh(xq + 0.05 * k, yq, -0.8 - 0.4 * k + 0.1 * np.sin(3.0 * xq), uq, vq)
+        m = scenes.material(kd=(0.9, 0.8, 0.7), diffuse_tex=dt, alpha_tex=at, two_sided=k % 2, alpha_cutoff=cut)
+        b.load_mesh_instance(scenes.MeshData(quad.positions, quad.triangles, quad.texcoords, quad.tri_uvs, [m], None, [tex1, texn]))
+
+
+def _frame(cfg, w, h, spp, kw):
+    def make(host, orc=None):
+        p = scenes.frame_params(cfg, *H.host_funcs(host, orc), width=w, height=h, spp=spp)
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                setattr(p, k, T.f3(*v))
+            else:
+                setattr(p, k, v)
+        return p
+    return make
+
+
+CFG = scenes.CONFIGS[2]
+CASES = {
+    "degenerate_spheres": (_degenerate_spheres(), scenes.Config("d", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 0.6, 0.0), max_depth=4), {}),
+    "nonfinite_spheres": (_nonfinite_spheres(), scenes.Config("n", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 0.6, 0.0), max_depth=3), {}),
+    "degenerate_mesh": (_degenerate_mesh, scenes.CONFIGS[1], {}),
+    "odd_transforms": (_odd_transforms, scenes.Config("x", 0, 0, 0, (0.4, 1.8, 5.0), (0.0, 0.8, 0.0), max_depth=4), {}),
+    "odd_textures": (_odd_textures, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0)), {}),
+    "zero_sun_black_sky": (scenes.build_config2, CFG, dict(dirLightDir=(0.0, 0.0, 0.0), skyTintTop=(0.0, 0.0, 0.0), skyTintBottom=(0.0, 0.0, 0.0))),
+    "nonfinite_lights": (scenes.build_config2, CFG, dict(dirLightRadiance=(INF, 1.0, NAN), skyTintTop=(1e38, 0.5, 0.5), dirLightDir=(NAN, 1.0, 0.0))),
+    "depth_12_roulette": (scenes.build_config2, scenes.Config("r", 0, 0, 0, (0.0, 1.5, 5.5), (0.0, 1.2, 0.0), max_depth=12, extra=CFG.extra), {}),
+    "spp_zero_negative_frame": (scenes.build_config2, CFG, dict(spp=0, frame=-5)),
+    "spp_negative": (scenes.build_config2, CFG, dict(spp=-3, frame=2147483647)),
+}
+MODES = {"auto": 0, "fused": T.FLAG_MEGAKERNEL, "streamed": T.FLAG_STREAMED, "streamed_counting": T.FLAG_STREAMED | T.FLAG_COUNTERS,
+         "fused_reference_layout": T.FLAG_MEGAKERNEL | T.FLAG_REFERENCE_LAYOUT}
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("name", list(CASES))
+def test_hostile_input(orc, renderer, name):
+    builder, cfg, over = CASES[name]
+    w, h, spp = 96, 64, 2
+    so = orc.OrcScene(); builder(so)
+    p = _frame(cfg, w, h, spp, over)("orc", orc)
+    ref, oo = T.alloc_outputs(w, h)
+    ost = orc.render_frame(so.desc(), p, oo, None)
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    pg = _frame(cfg, w, h, spp, over)("hrt")
+    for mode, fl in MODES.items():
+        renderer.reset_history()
+        got, og = T.alloc_outputs(w, h)
+        st = renderer.render_params(pg, og, flags=fl)
+        H.assert_outputs_equal(ref, got)
+        if fl & T.FLAG_COUNTERS:
+            assert st.k[1].as_dict() == ost.k[1].as_dict(), mode
