@@ -139,3 +139,46 @@ def test_hostile_input(orc, renderer, name):
         H.assert_outputs_equal(ref, got)
         if fl & T.FLAG_COUNTERS:
             assert st.k[1].as_dict() == ost.k[1].as_dict(), mode
+
+
+def _prev_cam_variants(orc):
+    """prevCam records ReprojectToPrevPixel (RTRay.cs:339-360) divides by: zero field of view (tan 0 = 0 -> x / 0), zero aspect, a NaN
+    forward axis, a camera far behind the scene (z <= 1e-4 for every vertex)."""
+    base = scenes.frame_params(scenes.CONFIGS[2], *H.host_funcs("orc", orc), width=64, height=48, spp=1).cam
+    out = {}
+    for name in ("fov0", "aspect0", "nan_forward", "behind", "huge_fov"):
+        c = T.Camera.from_buffer_copy(base)
+        if name == "fov0": c.fovYRadians = 0.0
+        if name == "aspect0": c.aspect = 0.0
+        if name == "nan_forward": c.forward = T.f3(NAN, 0.0, -1.0)
+        if name == "behind": c.origin = T.f3(0.0, 1.0, -50.0)
+        if name == "huge_fov": c.fovYRadians = 1e20
+        out[name] = c
+    return out
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("variant", ["fov0", "aspect0", "nan_forward", "behind", "huge_fov"])
+def test_hostile_reuse_camera(orc, renderer, variant):
+    """Temporal + spatial reuse over three frames where the previous camera of frames 1 and 2 is degenerate."""
+    builder, cfg = scenes.build_textured_test_scene, scenes.Config("t", 0, 0, 0, (0.3, 1.3, 4.2), (0.0, 0.7, 0.0))
+    w, h, spp = 64, 48, 2
+    so = orc.OrcScene(); builder(so)
+    s = engine.Scene(); builder(s); renderer.commit(s)
+    bad_cam = _prev_cam_variants(orc)[variant]
+    for fl in (T.FLAG_MEGAKERNEL, T.FLAG_STREAMED):
+        renderer.reset_history()
+        A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+        for f in range(3):
+            p = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp, frame=f, reuse=True, prev_cam=bad_cam if f else None)
+            prev, cur = (B, A) if f % 2 == 0 else (A, B)
+            ref, oo = T.alloc_outputs(w, h)
+            for k, a in cur.items():
+                ref[k] = a; setattr(oo, k, a.ctypes.data)
+            po = T.Outputs()
+            for k, a in prev.items():
+                setattr(po, k, a.ctypes.data)
+            orc.render_frame(so.desc(), p, oo, po)
+            got, og = T.alloc_outputs(w, h)
+            renderer.render_params(p, og, flags=fl)
+            H.assert_outputs_equal(ref, got)
