@@ -562,6 +562,8 @@ struct PackedHost {
     bool blas_refit_ok = true;                               // every TriMesh BLAS can be refitted on the device
     bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
     int reach_leaves = 0;     // reachable TLAS leaves
+    bool nested = true;       // every reachable TLAS node's box lies inside its parent's, every fast-sphere instance's own box inside its leaf's:
+                              // what "the boxes above only accelerate" (TracerFlat, the second tree) needs; the builders guarantee it, an uploaded tree may not
     bool inst_once = false;   // the reachable TLAS leaves list every instance exactly once (a second tree over "the instances" answers the same queries)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
@@ -732,6 +734,11 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         }
         for (int64_t ii = 0; once && ii < nI; ii++) if (!seen[(size_t)ii]) once = false;
         out.inst_once = once;
+        auto inside = [](const NodeQ& c, const NodeQ& p) {
+            return c.lo.x >= p.lo.x && c.lo.y >= p.lo.y && c.lo.z >= p.lo.z && c.hi.x <= p.hi.x && c.hi.y <= p.hi.y && c.hi.z <= p.hi.z;      // false with a NaN
+        };
+        for (size_t i = 1; i < (size_t)nT; i++)
+            if ((reachableT < 0 || (int32_t)i < reachableT) && out.parent[i] >= 0 && !inside(out.tlas[i], out.tlas[(size_t)out.parent[i]])) out.nested = false;
     }
     alloc_nodes(nB, out.blas);
     {
@@ -999,9 +1006,24 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         out.n_tlasX = at;
     }
 
+    // fast-sphere instances: own box inside the box of the leaf that lists them
+    for (int64_t i = 0; out.nested && i < nT; i++)
+    {
+        const NodeQ& q = out.tlas[(size_t)i];
+        const int cnt = (int)((unsigned)__builtin_bit_cast(int, q.hi.w) >> 28), first = __builtin_bit_cast(int, q.lo.w);
+        if (cnt == 0 || !(reachableT < 0 || (int32_t)i < reachableT)) continue;
+        for (int j = 0; j < cnt; j++)
+        {
+            if ((int64_t)first + j < 0 || (int64_t)first + j >= nTI) { out.nested = false; break; }
+            const FInst& f = out.finst[(size_t)(first + j)];
+            if (!(__builtin_bit_cast(int, f.a.w) & FI_FAST_SPHERE)) continue;
+            if (!(f.a.x >= q.lo.x && f.a.y >= q.lo.y && f.a.z >= q.lo.z && f.b.x <= q.hi.x && f.b.y <= q.hi.y && f.b.z <= q.hi.z)) { out.nested = false; break; }
+        }
+    }
+    if (!out.nested) out.inst_once = false;
     // TracerFlat: the reachable TLAS leaves in walk order, for scenes made of fast-sphere instances only
     out.flat.assign(1, NodeQ{});
-    if (out.ok && out.feat == 0 && reachableT > 0)
+    if (out.ok && out.feat == 0 && reachableT > 0 && out.nested)
     {
         std::vector<NodeQ> leaves;
         for (int32_t i = 0; i < reachableT; i++)

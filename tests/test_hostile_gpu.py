@@ -182,3 +182,43 @@ def test_hostile_reuse_camera(orc, renderer, variant):
             got, og = T.alloc_outputs(w, h)
             renderer.render_params(p, og, flags=fl)
             H.assert_outputs_equal(ref, got)
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("kind", ["inner_node_shrunk", "leaf_shrunk", "instance_listed_twice", "instance_left_out"])
+def test_hand_made_trees(orc, renderer, kind):
+    """Trees no builder makes, uploaded as raw arrays: a TLAS box that does not contain what is below it (the reference prunes there;
+    shortcuts that rely on nested boxes must stand down), an instance listed by two leaves, an instance no leaf lists."""
+    for builder, cfg, n in ((scenes.build_config2, scenes.CONFIGS[2], None),
+                            (lambda b: scenes.build_random_spheres(b, 399, seed=0xABCDEF, extent=5.0), scenes.Config("r", 0, 0, 0, (0.0, 3.0, 9.0), (0.0, 0.8, 0.0)), 400)):
+        so = orc.OrcScene(); builder(so)
+        arrs = so.arrays()
+        nodes, idx = arrs["tlasNodes"], arrs["tlasInstanceIndices"]
+        inner = [i for i in range(1, len(nodes)) if nodes[i]["count"] == 0]
+        leaves = [i for i in range(len(nodes)) if nodes[i]["count"] > 0]
+        if kind == "inner_node_shrunk":
+            i = inner[len(inner) // 2]
+            nodes[i]["boundsMax"]["X"] = nodes[i]["boundsMin"]["X"] + 0.25 * (nodes[i]["boundsMax"]["X"] - nodes[i]["boundsMin"]["X"])
+        elif kind == "leaf_shrunk":
+            i = leaves[len(leaves) // 2]
+            nodes[i]["boundsMin"]["Y"] = nodes[i]["boundsMax"]["Y"] - 0.3 * (nodes[i]["boundsMax"]["Y"] - nodes[i]["boundsMin"]["Y"])
+        elif kind == "instance_listed_twice":
+            a, b = leaves[1], leaves[-1]
+            idx[nodes[b]["first"]] = idx[nodes[a]["first"]]
+        elif kind == "instance_left_out":
+            a = leaves[len(leaves) // 3]
+            idx[nodes[a]["first"]] = idx[nodes[a]["first"] + nodes[a]["count"] - 1] if nodes[a]["count"] > 1 else idx[nodes[leaves[0]]["first"]]
+        desc, keep = T.scene_desc_from_arrays(arrs)
+        w, h, spp = 128, 72, 2
+        p = scenes.frame_params(cfg, *H.host_funcs("orc", orc), width=w, height=h, spp=spp)
+        ref, oo = T.alloc_outputs(w, h)
+        ost = orc.render_frame(desc, p, oo, None)
+        renderer.commit(desc)
+        pg = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+        for mode, fl in MODES.items():
+            renderer.reset_history()
+            got, og = T.alloc_outputs(w, h)
+            st = renderer.render_params(pg, og, flags=fl)
+            H.assert_outputs_equal(ref, got)
+            if fl & T.FLAG_COUNTERS:
+                assert st.k[1].as_dict() == ost.k[1].as_dict(), mode
