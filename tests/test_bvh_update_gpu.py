@@ -45,6 +45,12 @@ def _moves(n_inst, kind):
     for k, i in enumerate(ids):
         if kind == "identity":
             xfs.append(T.identity_affine())
+        elif kind == "hostile":      # zero / negative / huge uniform scale, a NaN and an infinite entry, a shear (columns of unequal length)
+            m = scenes.rotation_affine("xyz"[k % 3], 23.0 * k, [0.0, -1.3, 1e19, 1.0, 0.6, 1.0][k % 6], (0.2 * (k % 4) - 0.3, 0.1 * (k % 3), 0.2 * (k % 5) - 0.4))
+            if k % 6 == 3: m.m12 = float("nan")
+            if k % 6 == 4: m.m03 = float("inf")
+            if k % 6 == 5: m.m01 = 0.7; m.m22 = 2.5
+            xfs.append(m)
         elif kind == "translate":
             xfs.append(scenes.rotation_affine("y", 0.0, 1.0 if k % 3 else 0.75, (0.3 * (k % 4) - 0.4, 0.1 * (k % 3), 0.25 * (k % 5) - 0.5)))
         elif k % 2 == 0:
@@ -172,7 +178,7 @@ def test_refit_without_moves_reproduces_the_uploaded_tree(orc, renderer, name):
     _check_frames(orc, renderer, so.desc(), cfg, w, h, spp)
 
 
-@pytest.mark.parametrize("kind", ["rigid", "identity"])
+@pytest.mark.parametrize("kind", ["rigid", "identity", "hostile"])
 @pytest.mark.parametrize("name", list(SCENES))
 def test_refit_after_moves(orc, renderer, name, kind):
     builder, cfg, w, h, spp = SCENES[name]
