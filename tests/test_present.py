@@ -70,7 +70,8 @@ def test_pow_family_bit_exact_on_gpu(orc, renderer, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("out_size,scale", [((192, 108), 0.67), ((160, 90), 1.0), ((131, 77), 0.5)])
+@pytest.mark.parametrize("out_size,scale", [((192, 108), 0.67), ((160, 90), 1.0), ((131, 77), 0.5),
+                                            ((1, 1), 1.0), ((3, 2), 0.5), ((257, 3), 0.67), ((2, 199), 0.3), ((64, 48), 0.01)])   # degenerate sizes: 1-pixel inputs and outputs
 def test_present_matches_oracle(orc, renderer, out_size, scale):
     """render_direct (renderScale, two launches, presentation) for 4 frames with a moving sun: TAAU history
     accumulates on both sides; resample mode checked on the same low-res frames."""
