@@ -179,26 +179,26 @@ hrt_wf_closest_kernel(TR tr, FrameK k, WfBuffers W, int vsel, int depth, unsigne
 // persistent-wave walk kernels (packed layout only) + the finish kernel that shades the winners
 // ALT: `tr` walks the device-built tree over the same fast-sphere instances (boolean queries do not depend on the tree,
 // hrt_walker.hpp); `exact` is the uploaded tree, for rays whose slab arithmetic is not finite
-template <int FEAT, bool COUNT, bool ALT = false>
+template <int FEAT, bool COUNT, bool ALT = false, int LT = 2>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
 hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, WfBuffers W, int vsel, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_shadow_wave<FEAT, COUNT, ALT>(tr, exact, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
+    wf_walk_shadow_wave<FEAT, COUNT, ALT, LT>(tr, exact, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
     C.flush(counters);
 }
 
 // EXISTS: the closest-hit walk of the last bounce, where only hit-or-miss is used (hrt_walker.hpp)
-template <int FEAT, bool COUNT, bool EXISTS = false, bool ALT = false>
+template <int FEAT, bool COUNT, bool EXISTS = false, bool ALT = false, int LT = 2>
 __global__ void __launch_bounds__(256, HRT_WF_TRACE_WAVES)
 hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, WfBuffers W, int depth, int chained, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walk_closest_wave<FEAT, COUNT, EXISTS, ALT>(tr, exact, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
+    wf_walk_closest_wave<FEAT, COUNT, EXISTS, ALT, LT>(tr, exact, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
 
@@ -1266,7 +1266,10 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                             hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, vsel, depth, chained, cnt1);
                             return;
                         }
-                    hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, vsel, depth, chained, cnt1);
+                    if (F != 0 && d.dpacked.leafTris == 3)
+                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false, false, (F != 0 ? 3 : 2)>), chained ? gridW : gridR, block, 0, st, tr, tr, W, vsel, depth, chained, cnt1);
+                    else
+                        hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, vsel, depth, chained, cnt1);
                 };
                 // with a second tree every production walk of the frame uses it, and so does the shading of their winners (leaf
                 // slots are the second tree's)
@@ -1288,8 +1291,15 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                             else            hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, false, true>), chained ? gridW : gridR, block, 0, st, trAny, tr, W, depth, chained, cnt1);
                             return;
                         }
-                    if (!lastBounce) { hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1); return; }
-                    hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
+                    const bool lt3 = F != 0 && d.dpacked.leafTris == 3;
+                    if (!lastBounce)
+                    {
+                        if (lt3) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, false, false, (F != 0 ? 3 : 2)>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
+                        else     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
+                        return;
+                    }
+                    if (lt3) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true, false, (F != 0 ? 3 : 2)>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
+                    else     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
                 };
                 if (count)
                 {
@@ -1626,6 +1636,15 @@ try {
         d.dpacked.nTlas = (int)ph.tlas.size();
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
+        {   // triangle records per leaf step of the walker: three where leaves of three outnumber the fuller ones, else two (hrt_walker.hpp)
+            size_t n3 = 0, n4 = 0;
+            for (const NodeQ& q : ph.blas)
+            {
+                const unsigned cnt = (unsigned)__builtin_bit_cast(int, q.hi.w) >> 28;
+                if (cnt == 3) n3++; else if (cnt >= 4) n4++;
+            }
+            d.dpacked.leafTris = n3 > n4 ? 3 : 2;
+        }
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
         if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once)) return rcB;
     }

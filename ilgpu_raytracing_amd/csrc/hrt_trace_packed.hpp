@@ -54,6 +54,7 @@ struct DPacked {
     int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
     const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
+    int leafTris;            // triangle records the walker fetches per leaf step (2 or 3: hrt_walker.hpp)
     const int* slotMap;      // second tree over the same instances (hrt_walker.hpp, ALT): leaf slot of the uploaded tree -> leaf slot here; else nullptr
 };
 

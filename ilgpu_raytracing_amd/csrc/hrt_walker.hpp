@@ -65,7 +65,8 @@ __device__ unsigned long long g_walk_stats[2][24];
 // exactly the closest t so far, or a winner whose own slab entry exceeds its hit distance, sends the ray to the uploaded tree at
 // retirement (none in practice).  Results carry leaf slots of `tr`'s tree (DPacked::slotMap translates the uploaded tree's), so
 // the shading that follows reads `tr`'s instance records.
-template <int FEAT, bool ANY, bool COUNT, bool EXISTS, bool ALT, class NextSeg, class Fetch, class Done>
+// LT: triangle records fetched per leaf step (2 or 3; chosen per scene at upload, DPacked::leafTris).
+template <int FEAT, bool ANY, bool COUNT, bool EXISTS, bool ALT, int LT, class NextSeg, class Fetch, class Done>
 HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, NextSeg nextSeg, Fetch fetch, Done done, Cnt<COUNT>& C)
 {
     static_assert(!(EXISTS && (ANY || COUNT)), "EXISTS is a closest-hit walk of a production frame");
@@ -292,57 +293,70 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
             }
             else
             {
-                FTri trr = P.ftri[bj];
-                C.inc(C_TRI_TESTS);
-                float t, bu, bv;
-                if (hit_tri_t(w, xyz(trr.v0), xyz(trr.v1), xyz(trr.v2), t, bu, bv))
+                // the next one or two triangles of the leaf leave together with this one: a leaf costs one memory round trip per
+                // two or three triangles instead of one per triangle (three where most leaves hold three: the median split of
+                // config 4's mesh; two where they hold four: config 5's -- measured; LT follows DPacked::leafTris, chosen at upload).  The tests
+                // stay sequential per lane, in leaf order.
+                FTri trs[LT];
+#pragma unroll
+                for (int q = 0; q < LT; q++) trs[q] = P.ftri[bj + q < bend ? bj + q : bend - 1];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < LT; q++)
                 {
-                    if (!ANY)
-                    {   // TraverseBLAS_Tri_Textured :196-227
-                        C.inc(C_TRI_MT_HITS);
-                        if (t > 0.001f && t < tObj)
-                        {
-                            C.inc(C_TRI_ACCEPTED);
-                            bool accept = true;
+                    if (q > 0) { if (!(mode == M_BLEAF && bj + 1 < bend)) break; bj++; }
+                    const FTri trr = trs[q];
+                    C.inc(C_TRI_TESTS);
+                    float t, bu, bv;
+                    if (hit_tri_t(w, xyz(trr.v0), xyz(trr.v1), xyz(trr.v2), t, bu, bv))
+                    {
+                        if (!ANY)
+                        {   // TraverseBLAS_Tri_Textured :196-227
+                            C.inc(C_TRI_MT_HITS);
+                            if (t > 0.001f && t < tObj)
+                            {
+                                C.inc(C_TRI_ACCEPTED);
+                                bool accept = true;
+                                if (kAlpha && (wbits(trr.v2) & FT_TEXTURED))
+                                {
+                                    const hrt_material* mat = &S.materials[wbits(trr.v1)];
+                                    int ati = mat->AlphaTexIndex;
+                                    float alpha = 1.f;
+                                    if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
+                                    {
+                                        float uu, vv;
+                                        tr.tri_uv(wbits(trr.v0), bu, bv, uu, vv);
+                                        alpha = tex.mask_linear(S.texInfos[ati], uu, vv);
+                                    }
+                                    accept = !(alpha < mat->AlphaCutoff);
+                                }
+                                if (accept) { tObj = t; iprim = bj; }
+                                if (EXISTS && accept && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }
+                            }
+                        }
+                        else if (!(t <= 0.001f || t >= lim))
+                        {   // AnyHit_Tri_Textured :292-317
+                            C.inc(C_TRI_MT_HITS);
+                            bool blocked = true;
                             if (kAlpha && (wbits(trr.v2) & FT_TEXTURED))
                             {
                                 const hrt_material* mat = &S.materials[wbits(trr.v1)];
                                 int ati = mat->AlphaTexIndex;
-                                float alpha = 1.f;
                                 if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
                                 {
+                                    C.inc(C_TRI_ACCEPTED);
                                     float uu, vv;
                                     tr.tri_uv(wbits(trr.v0), bu, bv, uu, vv);
-                                    alpha = tex.mask_linear(S.texInfos[ati], uu, vv);
+                                    hrt_tex_info ainfo = S.texInfos[ati];
+                                    float aPoint = tex.mask_point(ainfo, uu, vv);
+                                    float cutoff = mat->AlphaCutoff;
+                                    if (aPoint < cutoff - 0.10f) blocked = false;
+                                    else if (aPoint >= cutoff + 0.10f) blocked = true;
+                                    else blocked = !(tex.mask_linear(ainfo, uu, vv) < cutoff);
                                 }
-                                accept = !(alpha < mat->AlphaCutoff);
                             }
-                            if (accept) { tObj = t; iprim = bj; }
-                            if (EXISTS && accept && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }
+                            if (blocked) { occl = true; mode = M_DONE; }
                         }
-                    }
-                    else if (!(t <= 0.001f || t >= lim))
-                    {   // AnyHit_Tri_Textured :292-317
-                        C.inc(C_TRI_MT_HITS);
-                        bool blocked = true;
-                        if (kAlpha && (wbits(trr.v2) & FT_TEXTURED))
-                        {
-                            const hrt_material* mat = &S.materials[wbits(trr.v1)];
-                            int ati = mat->AlphaTexIndex;
-                            if (mat->HasAlphaMap != 0 && ati >= 0 && ati < S.n_texInfos)
-                            {
-                                C.inc(C_TRI_ACCEPTED);
-                                float uu, vv;
-                                tr.tri_uv(wbits(trr.v0), bu, bv, uu, vv);
-                                hrt_tex_info ainfo = S.texInfos[ati];
-                                float aPoint = tex.mask_point(ainfo, uu, vv);
-                                float cutoff = mat->AlphaCutoff;
-                                if (aPoint < cutoff - 0.10f) blocked = false;
-                                else if (aPoint >= cutoff + 0.10f) blocked = true;
-                                else blocked = !(tex.mask_linear(ainfo, uu, vv) < cutoff);
-                            }
-                        }
-                        if (blocked) { occl = true; mode = M_DONE; }
                     }
                 }
             }

@@ -434,12 +434,12 @@ struct RangeGrab {
     }
 };
 
-template <int FEAT, bool COUNT, bool ALT>
+template <int FEAT, bool COUNT, bool ALT, int LT>
 HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntS + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, true, COUNT, false, ALT>(tr, exact,
+    walk_queue<FEAT, true, COUNT, false, ALT, LT>(tr, exact,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int q, Ray& r, float& tMax) {
             const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
@@ -450,12 +450,12 @@ HRT_D void wf_walk_shadow_wave(const TracerPackedT<FEAT>& tr, const TracerPacked
         }, C);
 }
 
-template <int FEAT, bool COUNT, bool EXISTS, bool ALT>
+template <int FEAT, bool COUNT, bool EXISTS, bool ALT, int LT>
 HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& exact, const WfBuffers& W, int depth, int* grabCtr, int ownRange, Cnt<COUNT>& C)
 {
     RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
     const int* cnt = W.cntA + (size_t)depth * W.nRanges;
-    walk_queue<FEAT, false, COUNT, EXISTS, ALT>(tr, exact,
+    walk_queue<FEAT, false, COUNT, EXISTS, ALT, LT>(tr, exact,
         [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
         [&](int slot, Ray& r, float& tMax) {
             tMax = 1e30f;
