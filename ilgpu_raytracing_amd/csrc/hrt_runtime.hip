@@ -978,7 +978,9 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
     // one record per instance holding the box of its one-node BLAS; the walker treats them as nodes (count field 15), so the
     // instance box tests ride the node steps and their lookahead instead of costing a leaf step each.
     out.tlasX.assign(1, NodeQ{});
-    if (out.ok && out.feat == 0 && reachableT > 0 && nT + nTI < kEnd && !HRT_ENV("HRT_NO_INLINE_INSTANCES"))
+    bool leavesFit = true;                   // count code 15 marks an instance record in this stream: a leaf of 15 instances cannot be told from one
+    for (int64_t i = 0; i < nT; i++) if (((unsigned)__builtin_bit_cast(int, out.tlas[(size_t)i].hi.w) >> 28) > 14u) leavesFit = false;
+    if (out.ok && out.feat == 0 && reachableT > 0 && nT + nTI < kEnd && leavesFit && !HRT_ENV("HRT_NO_INLINE_INSTANCES"))
     {
         std::vector<int32_t> nidx((size_t)nT);
         int32_t at = 0;

@@ -222,3 +222,55 @@ def test_hand_made_trees(orc, renderer, kind):
             H.assert_outputs_equal(ref, got)
             if fl & T.FLAG_COUNTERS:
                 assert st.k[1].as_dict() == ost.k[1].as_dict(), mode
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("leaf_size", [15, 14, 9])
+def test_one_big_tlas_leaf(orc, renderer, leaf_size):
+    """A hand-made TLAS of one inner node over two leaves, one of them as full as the 4-bit count field allows (15 is also the
+    count code of an instance record in the walker's node stream: such a tree keeps the plain layout)."""
+    def build(b):
+        rng = scenes.XorShift32(4242)
+        ids = [b.add_sphere(scenes.sphere((0.0, -1000.0, 0.0), 1000.0, (0.6, 0.6, 0.6)))]
+        for i in range(leaf_size):
+            ids.append(b.add_sphere(scenes.sphere((rng.uniform(-3, 3), rng.uniform(0.2, 1.6), rng.uniform(-3, 3)), rng.uniform(0.2, 0.5),
+                                                  (rng.uniform(0.2, 0.9), rng.uniform(0.2, 0.9), rng.uniform(0.2, 0.9)), [T.SHADING_LAMBERT, T.SHADING_MIRROR, T.SHADING_GLASS][i % 3], 1.5)))
+        for i in ids:
+            b.build_sphere_instance([i])
+        b.rebuild_tlas()
+    so = orc.OrcScene(); build(so)
+    arrs = so.arrays()
+    inst = arrs["instances"]
+    n = len(inst)
+    nodes = np.zeros(3, dtype=arrs["tlasNodes"].dtype)
+    def box(ids):
+        lo = [min(float(inst[i]["worldBoundsMin"][a]) for i in ids) for a in "XYZ"]
+        hi = [max(float(inst[i]["worldBoundsMax"][a]) for i in ids) for a in "XYZ"]
+        return lo, hi
+    def put(k, ids, **kw):
+        lo, hi = box(ids)
+        for a, v in zip("XYZ", lo): nodes[k]["boundsMin"][a] = v
+        for a, v in zip("XYZ", hi): nodes[k]["boundsMax"][a] = v
+        for f, v in kw.items(): nodes[k][f] = v
+    # walk order: root 0, left child 1 (the big leaf), right child 2 (the ground)
+    put(0, range(n), left=1, right=2, first=-1, count=0, skipIndex=-1)
+    put(1, range(1, n), left=-1, right=-1, first=0, count=leaf_size, skipIndex=2)
+    put(2, [0], left=-1, right=-1, first=leaf_size, count=1, skipIndex=-1)
+    arrs["tlasNodes"] = nodes
+    arrs["tlasInstanceIndices"] = np.array(list(range(1, n)) + [0], np.int32)
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    cfg = scenes.Config("big", 0, 0, 0, (0.0, 2.5, 8.0), (0.0, 0.7, 0.0), max_depth=4)
+    w, h, spp = 112, 64, 2
+    p = scenes.frame_params(cfg, *H.host_funcs("orc", orc), width=w, height=h, spp=spp)
+    ref, oo = T.alloc_outputs(w, h)
+    ost = orc.render_frame(desc, p, oo, None)
+    assert int(ref["gb_hitMask"].sum()) > 0 and len(np.unique(ref["color"])) > 50
+    renderer.commit(desc)
+    pg = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+    for mode, fl in MODES.items():
+        renderer.reset_history()
+        got, og = T.alloc_outputs(w, h)
+        st = renderer.render_params(pg, og, flags=fl)
+        H.assert_outputs_equal(ref, got)
+        if fl & T.FLAG_COUNTERS:
+            assert st.k[1].as_dict() == ost.k[1].as_dict(), mode
