@@ -644,6 +644,7 @@ struct FrameK {          // scalar part of GBufferParams / IntegratorParams (RTR
     int32_t row_begin, row_end, strip_n, strip_i;   // tile: 8-row strips s of [row_begin,row_end) with s % strip_n == strip_i
     hrt_camera cam, prevCam;
     hrt_float3 dirLightDir, dirLightRadiance, skyTop, skyBottom;
+    hrt_float3 dirLightN;    // Normalize(dirLightDir), evaluated once per frame on the host (hrt_runtime.hip, frame_k)
     int32_t debugCamSeq, enableTemporal, enableSpatial, rngLockNoise, spp, maxDepth;
 };
 
@@ -823,7 +824,7 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
         reservoir_update(r, wi, luminance(f_over_p), 1, rng);
     }
     {
-        F3 wi = normalize(cv3(k.dirLightDir));
+        F3 wi = cv3(k.dirLightN);                  // Float3.Normalize(k.dirLightDir), :464
         float nl = hrt_fmax(0.f, dot(n, wi));
         float pdfSel = hrt_fmax(kEPS_MIN, mixDelta);
         F3 LiDir = cv3(k.dirLightRadiance);

@@ -2080,6 +2080,12 @@ try {
         k.row_begin = d.row_begin; k.row_end = d.row_end; k.strip_n = d.strip_n; k.strip_i = d.strip_i;
         k.cam = p->cam; k.prevCam = p->prevCam;
         k.dirLightDir = p->dirLightDir; k.dirLightRadiance = p->dirLightRadiance;
+        {   // Float3.Normalize(k.dirLightDir) (RTRay.cs:464) is the same for every vertex of the frame: evaluated here, by the contract's
+            // host definitions (IEEE sqrt and division, maxNum: include/hrt_math.h), instead of at every diffuse vertex on the device
+            const float x = p->dirLightDir.X, y = p->dirLightDir.Y, z = p->dirLightDir.Z;
+            const float inv = hrt_rsqrt(hrt_fmax(1e-20f, x * x + y * y + z * z));
+            k.dirLightN.X = x * inv; k.dirLightN.Y = y * inv; k.dirLightN.Z = z * inv;
+        }
         k.skyTop = p->skyTintTop; k.skyBottom = p->skyTintBottom;
         k.debugCamSeq = p->debugCamSeq; k.enableTemporal = p->enableTemporalReuse; k.enableSpatial = p->enableSpatialReuse;
         k.rngLockNoise = p->rngLockNoise; k.spp = p->spp; k.maxDepth = p->maxDepth;
