@@ -898,7 +898,9 @@ struct SplitK {
     int sBegin, sEnd, group, nGroups;
     int local, nLocal;       // this lane's slot in the scratch planes and their length: lanes of the launch's tiles, not image pixels
 };
-template <class TR, bool COUNT, bool SPLIT = false>
+// REUSE = false: a frame with both ReSTIR reuse switches off (the launch knows); the import code and the arguments only it reads
+// (previous reservoirs, previous camera) are compiled out instead of being carried -- and spilled -- through the bounce loop.
+template <class TR, bool COUNT, bool SPLIT = false, bool REUSE = true>
 HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, const DFramebuffer& fb,
                             const DReservoir& resPrev, const DReservoir& resCur, int64_t nPix, int index, Cnt<COUNT>& C, const SplitK* sk = nullptr)
 {
@@ -1013,7 +1015,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 {   // :277-317
                     PSTAT(3);
                     Frame fr = make_frame(nrm);
-                    Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !wroteReservoir, pos, fr, alb, rng, C);
+                    Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, REUSE && !wroteReservoir, pos, fr, alb, rng, C);
                     // (5) final shading with one visibility ray :518-539
                     F3 contrib = mk3(0.f, 0.f, 0.f);
                     if (r.m > 0 && r.wSum > 0.f && r.w > 0.f)

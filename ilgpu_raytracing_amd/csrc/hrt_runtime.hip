@@ -71,14 +71,14 @@ template <class TR> struct PtWaves { static constexpr int value = HRT_PT_WAVES; 
 #define HRT_PT_WAVES_FLAT (HRT_PT_WAVES + 1)
 #endif
 template <> struct PtWaves<TracerFlat> { static constexpr int value = HRT_PT_WAVES_FLAT; };
-template <class TR, bool COUNT>
+template <class TR, bool COUNT, bool REUSE = true>
 __global__ void __launch_bounds__(256, PtWaves<TR>::value)
 hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
                       long long nPix, TileMap tm, unsigned long long* counters)
 {
     Cnt<COUNT> C;
     int x, y;
-    if (tile_pixel(tm, k, x, y, blockIdx.x)) path_trace_pixel<TR, COUNT>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
+    if (tile_pixel(tm, k, x, y, blockIdx.x)) path_trace_pixel<TR, COUNT, false, REUSE>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C);
     C.flush(counters);
 }
 
@@ -86,7 +86,7 @@ hrt_path_trace_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir 
 // fills the machine for about one round, and the launch lasts as long as its slowest wave.  The samples of a pixel are
 // independent up to the ordered sum and the last-writer reservoir, so the launch is cut into sample groups (workgroup =
 // tile x group) and a resolve pass puts the pixel together in sample order: same values, several rounds of shorter waves.
-template <class TR>
+template <class TR, bool REUSE = true>
 __global__ void __launch_bounds__(256, PtWaves<TR>::value)
 hrt_path_trace_split_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DReservoir resPrev, DReservoir resCur,
                             long long nPix, TileMap tm, hrt_float3* li, float* stage, int nGroups, int perGroup)
@@ -99,7 +99,7 @@ hrt_path_trace_split_kernel(TR tr, FrameK k, DGBuffer gb, DFramebuffer fb, DRese
     const int tileBlock = blockIdx.x - g * tm.nTiles;
     sk.local = tileBlock * (int)blockDim.x + (int)threadIdx.x; sk.nLocal = tm.nTiles * (int)blockDim.x;
     int x, y;
-    if (tile_pixel(tm, k, x, y, tileBlock)) path_trace_pixel<TR, false, true>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C, &sk);
+    if (tile_pixel(tm, k, x, y, tileBlock)) path_trace_pixel<TR, false, true, REUSE>(tr, k, gb, fb, resPrev, resCur, nPix, y * k.width + x, C, &sk);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1134,6 +1134,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     if (mega || k.maxDepth > 64)
     {
         const dim3 grid(tm.nTiles), block(64 * tm.wpb);
+        // frames without ReSTIR reuse: the leaf-sweep tracer's kernels with the import code compiled out (hrt_device.hpp, REUSE)
+        const bool noReuse = std::is_same<TR, TracerFlat>::value && !count && k.enableTemporal == 0 && k.enableSpatial == 0;
         // sample groups when the tile gives the machine less than ~5 rounds of waves
         static const int splitEnv = HRT_ENV("HRT_SPLIT") ? atoi(HRT_ENV("HRT_SPLIT")) : -1;          // A/B knob: 0 never, n > 0 force n groups
         const int sppN = k.spp > 1 ? k.spp : 1;
@@ -1160,12 +1162,14 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
             }
             hrt_float3* li = (hrt_float3*)d.split_mem;
             float* stage = d.split_mem + (size_t)sppN * 3 * nLocal;
-            hipLaunchKernelGGL((hrt_path_trace_split_kernel<TR>), dim3(tm.nTiles * nGroups), block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, li, stage, nGroups, perGroup);
+            if (noReuse) { if constexpr (std::is_same<TR, TracerFlat>::value) hipLaunchKernelGGL((hrt_path_trace_split_kernel<TR, false>), dim3(tm.nTiles * nGroups), block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, li, stage, nGroups, perGroup); }
+            else hipLaunchKernelGGL((hrt_path_trace_split_kernel<TR>), dim3(tm.nTiles * nGroups), block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, li, stage, nGroups, perGroup);
             hipLaunchKernelGGL(hrt_split_resolve_kernel, grid, block, 0, d.stream, k, d.gb, d.fb, resCur, nPix, tm, (const hrt_float3*)li, (const float*)stage, nGroups);
             HIPCHK(c, hipGetLastError());
             return HRT_OK;
         }
         if (count) hipLaunchKernelGGL((hrt_path_trace_kernel<TR, true>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
+        else if (noReuse) { if constexpr (std::is_same<TR, TracerFlat>::value) hipLaunchKernelGGL((hrt_path_trace_kernel<TR, false, false>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1); }
         else       hipLaunchKernelGGL((hrt_path_trace_kernel<TR, false>), grid, block, 0, d.stream, tr, k, d.gb, d.fb, resPrev, resCur, nPix, tm, cnt1);
         HIPCHK(c, hipGetLastError());
         return HRT_OK;
