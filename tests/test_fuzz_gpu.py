@@ -1,0 +1,171 @@
+"""Seeded differential fuzz of the render path: random small scenes (sphere sets with every shading kind, multi-sphere instances built
+before and after their spheres' neighbours, rigid / scaled / identity transforms, 0-3 textured or alpha-cut meshes), random cameras,
+lights and frame parameters (spp, maxDepth 0..7, frame number, locked noise, ReSTIR reuse over two frames) -- every output array of
+every frame against the oracle, in the kernel organisation the library picks and in one forced organisation per case.
+HRT_FUZZ_CASES / HRT_FUZZ_SEED override the number of cases and the first seed (one-off deep runs of this round: 3 000 + 20 000 cases)."""
+import os
+
+import numpy as np
+import pytest
+
+from ilgpu_raytracing_amd import _types as T, scenes, engine
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("HRT_FUZZ_CASES", "0")) or 120
+SEED0 = int(os.environ.get("HRT_FUZZ_SEED", "0"), 0) or 0x5EED0000
+FORCED = [T.FLAG_MEGAKERNEL, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS, T.FLAG_MEGAKERNEL | T.FLAG_REFERENCE_LAYOUT, T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT]
+
+
+def _scene_recipe(seed):
+    """A list of builder operations (applied alike to the oracle's scene and the library's) + frame settings."""
+    rng = np.random.default_rng(seed)
+    ops = []
+    n_sph = int(rng.integers(1, 28))
+    shading = lambda: int(rng.choice([T.SHADING_LAMBERT] * 5 + [T.SHADING_MIRROR, T.SHADING_GLASS]))
+    if rng.random() < 0.8:
+        ops.append(("sphere", (0.0, -200.0, 0.0), 200.0, tuple(float(v) for v in rng.uniform(0.3, 0.9, 3)), T.SHADING_LAMBERT, 1.0, True))
+    pending = []
+    for i in range(n_sph):
+        c = (float(rng.uniform(-3, 3)), float(rng.uniform(0.05, 2.0)), float(rng.uniform(-3, 3)))
+        ops.append(("sphere", c, float(rng.uniform(0.08, 0.7)), tuple(float(v) for v in rng.uniform(0.05, 1.0, 3)), shading(), float(rng.choice([1.0, 1.33, 1.5, 2.4])), False))
+        pending.append(i)
+        if rng.random() < 0.45 or i == n_sph - 1:          # flush the pending spheres as one or several instances
+            while pending:
+                k = int(rng.integers(1, min(len(pending), 6) + 1))
+                group, pending = pending[:k], pending[k:]
+                kind = rng.random()
+                if kind < 0.6: xf = None
+                elif kind < 0.8: xf = ("y", 0.0, 1.0, tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3)))
+                else: xf = (str(rng.choice(list("xyz"))), float(rng.uniform(-80, 80)), float(rng.choice([0.5, 0.8, 1.0, 1.3])), tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3)))
+                ops.append(("instance", group, xf))
+    for m in range(int(rng.choice([0, 0, 1, 1, 2, 3]))):
+        n = int(rng.integers(1, 6))
+        s = np.linspace(-1.0, 1.0, n + 1)
+        yq, xq = np.meshgrid(s * rng.uniform(0.3, 1.0) + rng.uniform(0.3, 1.5), s * rng.uniform(0.3, 1.2) + rng.uniform(-1.5, 1.5), indexing="ij")
+        zq = rng.uniform(-2.0, 1.0) + rng.uniform(0.0, 0.3) * np.sin(rng.uniform(1, 4) * xq) * np.cos(rng.uniform(1, 4) * yq)
+        tex = rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 4), dtype=np.uint8)
+        mask = rng.integers(0, 256, (int(rng.integers(1, 9)), int(rng.integers(1, 9)), 4), dtype=np.uint8)
+        mat = dict(kd=tuple(float(v) for v in rng.uniform(0.1, 1.0, 3)), diffuse_tex=int(rng.choice([-1, 0])), alpha_tex=int(rng.choice([-1, -1, 1])),
+                   two_sided=int(rng.integers(0, 2)), alpha_cutoff=float(rng.choice([0.3, 0.5, 0.7])))
+        xf = None if rng.random() < 0.5 else (str(rng.choice(list("xyz"))), float(rng.uniform(-60, 60)), float(rng.choice([0.6, 1.0, 1.4])), tuple(float(v) for v in rng.uniform(-0.6, 0.6, 3)))
+        uvs = (float(rng.uniform(0.5, 3.0)), float(rng.uniform(0.5, 3.0)))
+        ops.append(("mesh", xq, yq, zq, uvs, mat, tex, mask, xf))
+    frame = dict(origin=tuple(float(v) for v in (rng.uniform(-1.5, 1.5), rng.uniform(0.4, 3.0), rng.uniform(3.0, 7.0))),
+                 lookat=tuple(float(v) for v in (rng.uniform(-0.5, 0.5), rng.uniform(0.2, 1.2), rng.uniform(-0.5, 0.5))),
+                 vfov=float(rng.choice([35.0, 60.0, 90.0])), max_depth=int(rng.choice([0, 1, 2, 3, 3, 3, 4, 5, 7])), spp=int(rng.integers(1, 4)),
+                 frame=int(rng.choice([0, 1, 7, 123456, -3])), lock=int(rng.choice([0, 0, 0, 987654321, -5])), reuse=bool(rng.random() < 0.35),
+                 sun=(float(rng.uniform(0, 6.28)), float(rng.uniform(0.1, 1.5))), w=int(rng.choice([32, 40, 56])), h=int(rng.choice([24, 32, 40])))
+    return ops, frame
+
+
+def _apply(b, ops):
+    ids = []
+    for op in ops:
+        if op[0] == "sphere":
+            _, c, r, kd, sh, ior, own = op
+            sid = b.add_sphere(scenes.sphere(c, r, kd, sh, ior))
+            if own: b.build_sphere_instance([sid])
+            else: ids.append(sid)
+        elif op[0] == "instance":
+            _, group, xf = op
+            b.build_sphere_instance([ids[g] for g in group], None if xf is None else scenes.rotation_affine(*xf))
+        else:
+            _, xq, yq, zq, uvs, mat, tex, mask, xf = op
+            g = scenes.grid_mesh(xq, yq, zq, (xq - xq.min()) * uvs[0], (yq - yq.min()) * uvs[1])
+            m = scenes.material(**mat)
+            b.load_mesh_instance(scenes.MeshData(g.positions, g.triangles, g.texcoords, g.tri_uvs, [m], None, [tex, mask]), None if xf is None else scenes.rotation_affine(*xf))
+    b.rebuild_tlas()
+
+
+@pytest.mark.timeout(1800)
+def test_random_scenes_match_the_oracle(orc, renderer):
+    failures = []
+    for case in range(N_CASES):
+        seed = SEED0 + case
+        ops, fr = _scene_recipe(seed)
+        so = orc.OrcScene(); _apply(so, ops)
+        s = engine.Scene(); _apply(s, ops)
+        assert so.arrays()["instances"].tobytes() == s.arrays()["instances"].tobytes()
+        renderer.commit(s)
+        cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                            extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+        w, h = fr["w"], fr["h"]
+        for fl in (0, FORCED[case % len(FORCED)]):
+            renderer.reset_history()
+            A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+            for f in range(2 if fr["reuse"] else 1):
+                frame = fr["frame"] + f
+                po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+                pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+                prev, cur = (B, A) if (frame & 1) == 0 else (A, B)
+                ref, oo = T.alloc_outputs(w, h)
+                for k, a in cur.items():
+                    ref[k] = a; setattr(oo, k, a.ctypes.data)
+                po = T.Outputs()
+                for k, a in prev.items():
+                    setattr(po, k, a.ctypes.data)
+                ost = orc.render_frame(so.desc(), po_, oo, po)
+                got, og = T.alloc_outputs(w, h)
+                st = renderer.render_params(pg_, og, flags=fl)
+                bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+                bad = {k: v for k, v in bad.items() if v}
+                if not bad and (fl & T.FLAG_COUNTERS) and st.k[1].as_dict() != ost.k[1].as_dict():
+                    bad = {"counters": 1}
+                if bad:
+                    failures.append((seed, fl, f, bad))
+                    break
+        if len(failures) >= 5:
+            break
+    assert not failures, "cases that differ from the oracle (seed, flags, frame, {array: elements}): %s" % failures
+
+
+@pytest.mark.timeout(1800)
+def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer):
+    """256..700 one-sphere instances (the second, device-built TLAS is in use for every production walk), some of them exact
+    duplicates or near-duplicates of others (equal and almost equal distances), random extents and cameras."""
+    n_cases = max(6, N_CASES // 12)
+    failures = []
+    for case in range(n_cases):
+        rng = np.random.default_rng(SEED0 + 0x100000 + case)
+        n = int(rng.integers(256, 700))
+        ext = float(rng.choice([2.0, 5.0, 12.0]))
+        recs = [((0.0, -500.0, 0.0), 500.0, (0.6, 0.6, 0.6), T.SHADING_LAMBERT, 1.0)] if rng.random() < 0.7 else []
+        for i in range(n):
+            if recs and i > 4 and rng.random() < 0.15:           # a twin: same place, or a hair away, another material
+                c, r, _, _, _ = recs[int(rng.integers(1 if len(recs) > 1 else 0, len(recs)))]
+                if rng.random() < 0.5:
+                    c = tuple(np.float32(v) + np.float32(rng.choice([0.0, 1e-7, -1e-7])) for v in c)
+            else:
+                c, r = (float(rng.uniform(-ext, ext)), float(rng.uniform(0.05, 0.4 * ext)), float(rng.uniform(-ext, ext))), float(rng.uniform(0.03, 0.12) * ext)
+            recs.append((tuple(float(v) for v in c), float(r), tuple(float(v) for v in rng.uniform(0.1, 1.0, 3)),
+                         int(rng.choice([T.SHADING_LAMBERT] * 4 + [T.SHADING_MIRROR, T.SHADING_GLASS])), 1.5))
+        order = rng.permutation(len(recs))
+
+        def build(b):
+            ids = [b.add_sphere(scenes.sphere(*recs[int(j)])) for j in order]
+            for i in ids:
+                b.build_sphere_instance([i])
+            b.rebuild_tlas()
+        so = orc.OrcScene(); build(so)
+        s = engine.Scene(); build(s); renderer.commit(s)
+        cfg = scenes.Config("fz2", 64, 40, 2, (float(rng.uniform(-1, 1)) * ext, float(rng.uniform(0.3, 1.0)) * ext, 2.2 * ext), (0.0, 0.15 * ext, 0.0),
+                            max_depth=int(rng.choice([2, 3, 5])))
+        po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc))
+        ref, oo = T.alloc_outputs(64, 40)
+        ost = orc.render_frame(so.desc(), po_, oo, None)
+        pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"))
+        for fl in (0, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS, T.FLAG_MEGAKERNEL):
+            renderer.reset_history()
+            got, og = T.alloc_outputs(64, 40)
+            st = renderer.render_params(pg_, og, flags=fl)
+            bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+            bad = {k: v for k, v in bad.items() if v}
+            if not bad and (fl & T.FLAG_COUNTERS) and st.k[1].as_dict() != ost.k[1].as_dict():
+                bad = {"counters": 1}
+            if bad:
+                failures.append((case, fl, bad))
+                break
+        if len(failures) >= 5:
+            break
+    assert not failures, "cases that differ from the oracle (case, flags, {array: elements}): %s" % failures
