@@ -84,3 +84,26 @@ def test_second_restatement_reuse_frames(orc, moving):
         imported += st.k[1].reuse_imports
         prev_cam = T.Camera.from_buffer_copy(p.cam)
     assert imported > w * h                     # reuse really ran
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_second_restatement_on_random_scenes(orc, case):
+    """The scene / frame recipes of the GPU differential fuzz (tests/test_fuzz_gpu.py) at postage-stamp size: both restatements of the
+    reference must agree on every array, first frame and (where the recipe has reuse on) the second."""
+    from tests import test_fuzz_gpu as F
+    ops, fr = F._scene_recipe(0x0DD50000 + case)
+    so = orc.OrcScene()
+    F._apply(so, ops)
+    arrs = so.arrays()
+    w, h = 14, 10
+    cfg = scenes.Config("fz", w, h, min(fr["spp"], 2), fr["origin"], fr["lookat"], max_depth=min(fr["max_depth"], 4), vfov=fr["vfov"],
+                        extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+    A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+    for f in range(2 if fr["reuse"] else 1):
+        frame = fr["frame"] + f
+        prev, cur = (B, A) if (frame & 1) == 0 else (A, B)
+        mine = {k: a.copy() for k, a in cur.items()}
+        ref, _, p = H.oracle_frame(orc, lambda b: F._apply(b, ops), cfg, w, h, cfg.spp, frame=frame, reuse=fr["reuse"], lock=fr["lock"], prev=prev, cur=cur, nthreads=1)
+        got = orc_indep.render(arrs, p, _math(orc), prev=prev, cur=mine)
+        bad = _differences(got, ref)
+        assert not bad, "frame %d: the two restatements differ {array: elements}: %s" % (f, bad)
