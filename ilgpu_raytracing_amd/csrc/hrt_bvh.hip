@@ -885,14 +885,16 @@ hipError_t tlas_rebuild_topology(TlasDevice& T, hipStream_t s, int* leavesOut)
 // Second tree of a fast-sphere scene (hrt_trace_packed.hpp, "Closest-hit walks over the SECOND tree"): every node box -- not the
 // instance records inlined into tlasX, whose own test must stay the reference's -- grows by a slack that covers how far the
 // computed slab entry of an instance inside it can exceed the computed hit distance of its sphere:
-//   4 sqrt(2 rho 2^-24 m) + 2^-7 rho,  rho = half the node's longest side (>= any radius inside), m = its largest |coordinate|.
+//   4 sqrt(2 rho 2^-24 m) + 2^-7 rho + 2^-19 m,  rho = half the node's longest side (>= any radius inside), m = its largest |coordinate|
+// (the cap of a sphere outside its rounded box, the error of a grazing hit's t in units of the radius, a few ulps of the coordinates so
+// that a ray skimming a face within rounding of it is inside the slab; tests/test_second_tree_bound.py probes the sum).
 __device__ void inflate_box(float4& lo, float4& hi)
 {
     const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
     if (!(ex >= 0.f && ey >= 0.f && ez >= 0.f)) return;                 // empty / unset box
     const float rho = 0.5f * fmaxf(ex, fmaxf(ey, ez));
     const float m = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-    const float s = 1.0625f * (4.f * sqrtf(2.f * rho * 0x1p-24f * m) + 0x1p-7f * rho) + 1e-30f;
+    const float s = 1.0625f * (4.f * sqrtf(2.f * rho * 0x1p-24f * m) + 0x1p-7f * rho + 0x1p-19f * m) + 1e-30f;
     lo.x = nextafterf(lo.x - s, -INFINITY); lo.y = nextafterf(lo.y - s, -INFINITY); lo.z = nextafterf(lo.z - s, -INFINITY);
     hi.x = nextafterf(hi.x + s, INFINITY);  hi.y = nextafterf(hi.y + s, INFINITY);  hi.z = nextafterf(hi.z + s, INFINITY);
 }

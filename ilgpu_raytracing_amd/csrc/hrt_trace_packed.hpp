@@ -95,13 +95,21 @@ HRT_D float box_entry(const Ray& r, float4 lo, float4 hi)
 // The exception is a winner whose computed entry EXCEEDS its computed hit distance (rounding: the float box can be a fraction of
 // an ulp smaller than the sphere, and t of a grazing hit carries an absolute error of ~7e-4 of the distance), which a node test
 // with a closest t between the two can skip or not, depending on the order.  So:
-//   (1) the second tree's node boxes are inflated (hrt_bvh.hip, tlas_inflate) and its node tests take closest * kSecondLimit, so
-//       that no instance with t_i < closest is pruned even when its entry exceeds t_i by the bound below -- the walk finds the
-//       least t over ALL candidates;
+//   (1) the second tree's node boxes are inflated (hrt_bvh.hip, inflate_box) and its node tests take closest * kSecondLimit, so
+//       that no node holding an instance with a valid hit t_i < closest is pruned -- the walk finds the least t over ALL candidates;
 //   (2) a candidate at exactly the closest t so far (a tie), or a winner with tmin_w > t_w, sends the ray to the uploaded tree.
-// Bound used by (1), for a candidate of radius r at centre c hit at t: tmin - t <= 2^-8 t + 4 sqrt(2 r 2^-24 (|c|+r)) + 2^-7 r
-// (cap of the sphere outside its rounded box: chord 2 sqrt(2 r beta), beta = half an ulp of |c| + r; square-root amplification
-// of the discriminant's rounding at grazing incidence: sqrt(8 2^-24) (1.5 |o - c| + r) with |o - c| <= t + r; both doubled).
+// Why (1) holds.  The point o + t_i d of a valid hit -- a true one up to the rounding of t (at grazing incidence the square root
+// amplifies the discriminant's rounding to ~7e-4 of the distance), or the closest approach of a ray that misses by rounding --
+// lies within r (1 + 2^-8) + 2^-9 t_i of the centre, hence inside the instance's box grown by the cap of the sphere that its
+// rounded corners cut off (chord 2 sqrt(2 r beta), beta = half an ulp of |c| + r), by 2^-7 r, and by a few ulps of the
+// coordinates (a ray that skims a face within rounding of it computes that slab's entry with an error of ulp / |d_axis|, which
+// is unbounded for the tight box and harmless once the face has moved away by more than the ulp).  inflate_box grows every
+// node by at least that for anything inside it, so the node's computed entry is <= t_i (1 + 2^-8) < closest * (1 + 2^-7).
+// The instance's OWN test keeps the exact box and the limit 1e30: it is the reference's.  The computed entry of the TIGHT box
+// can exceed t_i by any amount in the skimming case, which is what (2) catches for the winner.
+// tests/test_second_tree_bound.py samples adversarial (ray, sphere) pairs -- pole and silhouette hits, axis-parallel and skimming
+// rays, coordinates from 1e-2 to 1e3, radii from 1e-3 of that up -- against "the grown box's computed entry <= t_i (1 + 2^-7)"
+// (27 million candidates in a one-off run, no exception).
 constexpr float kSecondLimit = 1.f + 0x1p-7f;
 
 // The world ray is dead weight while a general instance's BLAS is walked with the object-space
