@@ -387,6 +387,7 @@ struct hrt_ctx {
     int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
     int wide_depth = 0;                        // > 0: the 4-wide collapse exists; stack bound of the wide walker = 3 * wide_depth + 2
     int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
+    bool own_in_world = false;                 // PackedHost::own_in_world of the uploaded scene
     bool small_scene = false;                  // <= kSmallSceneNodes BVH nodes: the walk is ALU-bound and L1-resident -> megakernel
     // state of hrt_scene_update_instances
     bool refit_ok = false;                     // every reachable TLAS node has one parent and <= 64 children
@@ -564,6 +565,9 @@ struct PackedHost {
     int reach_leaves = 0;     // reachable TLAS leaves
     bool nested = true;       // every reachable TLAS node's box lies inside its parent's, every fast-sphere instance's own box inside its leaf's:
                               // what "the boxes above only accelerate" (TracerFlat, the second tree) needs; the builders guarantee it, an uploaded tree may not
+    bool own_in_world = true; // every fast-sphere instance's own box (its one-node BLAS) lies inside its worldBounds: a TLAS refitted or rebuilt on the
+                              // device (leaf boxes = unions of worldBounds) is then nested like the builder's; false e.g. for an instance whose BLAS
+                              // the position-indexed builder put over another sphere (Scene.cs:386-395)
     bool inst_once = false;   // the reachable TLAS leaves list every instance exactly once (a second tree over "the instances" answers the same queries)
     bool ok = true;           // false -> limits of the packed encoding exceeded (not an error)
     int feat = 0;             // TracerPackedT<FEAT> bits the committed scene needs
@@ -873,6 +877,8 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             f.c = mkf4(bits_f(in.blasRoot), bits_f(in.blasRoot + in.blasNodeCount), scale, 0.f);
         }
         out.finst[(size_t)i] = f;
+        if (fast && !(f.a.x >= in.worldBoundsMin.X && f.a.y >= in.worldBoundsMin.Y && f.a.z >= in.worldBoundsMin.Z &&
+                      f.b.x <= in.worldBoundsMax.X && f.b.y <= in.worldBoundsMax.Y && f.b.z <= in.worldBoundsMax.Z)) out.own_in_world = false;
     }
     out.ftri.resize((size_t)std::max<int64_t>(nTP, 1));
     std::memset(out.ftri.data(), 0, out.ftri.size() * sizeof(FTri));
@@ -1534,6 +1540,7 @@ try {
     c->packed_feat = (ph.feat & 2) ? 3 : (ph.feat & 1);
     c->small_scene = (s->n_tlasNodes + s->n_blasNodes) <= kSmallSceneNodes;
     c->flat_leaves = ph.n_flat;
+    c->own_in_world = ph.own_in_world;
     c->wide_depth = ph.wide_depth;
     c->refit_ok = ph.refit_ok && ph.ok;
     c->feat_alpha = (ph.feat & 2) != 0;
@@ -1843,7 +1850,9 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             out.growth_refit = growthRefit; out.growth_final = h_cost[0]; out.sah_cost = h_cost[1]; out.device_ms = ms;
             if (action == HRT_REBUILD_FORCE_REBUILD) { c->tlas_leaves = rebuiltLeaves; c->refit_ok = true; }
             c->packed_feat = c->feat_alpha ? 3 : (general ? 1 : 0);
-            c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
+            // the leaf sweep skips box tests the reference makes, which is only sound over nested boxes: the device's trees are unions of
+            // the instances' worldBounds, so it takes every fast-sphere instance's own box to lie inside its worldBounds
+            c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->own_in_world && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
             c->n_tlas = T.nT; c->n_slots = T.nTI;
             c->small_scene = (c->n_tlas + c->n_blas) <= kSmallSceneNodes;
             c->wide_depth = 0;                       // the 4-wide collapse is not maintained on the device

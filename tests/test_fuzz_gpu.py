@@ -169,3 +169,62 @@ def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer):
         if len(failures) >= 5:
             break
     assert not failures, "cases that differ from the oracle (case, flags, {array: elements}): %s" % failures
+
+
+@pytest.mark.timeout(1800)
+def test_random_moves_through_the_device_update_path(orc, renderer):
+    """Random scenes, then random instance moves (rigid, scaled, identity, a degenerate one now and then) under a random policy
+    (refit / rebuild / auto) on the device: the instance records must be the oracle's, and the frame must be the oracle's frame on
+    the tree the device made (downloaded)."""
+    from tests import test_bvh_update_gpu as U
+    n_cases = max(8, N_CASES // 4)
+    failures = []
+    for case in range(n_cases):
+        seed = SEED0 + 0x200000 + case
+        ops, fr = _scene_recipe(seed)
+        rng = np.random.default_rng(seed ^ 0xABCDEF)
+        so = orc.OrcScene(); _apply(so, ops)
+        s = engine.Scene(); _apply(s, ops)
+        renderer.commit(s)
+        n_inst = len(so.arrays()["instances"])
+        if n_inst < 2:
+            continue
+        ids = sorted(set(int(v) for v in rng.integers(0, n_inst, int(rng.integers(1, min(n_inst, 8) + 1)))))
+        xfs = []
+        for _ in ids:
+            k = rng.random()
+            if k < 0.15: xfs.append(T.identity_affine())
+            elif k < 0.9: xfs.append(scenes.rotation_affine(str(rng.choice(list("xyz"))), float(rng.uniform(-90, 90)), float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25])), tuple(float(v) for v in rng.uniform(-0.8, 0.8, 3))))
+            else: xfs.append(scenes.rotation_affine("y", 10.0, float(rng.choice([0.0, -1.0, 1e10])), (0.1, 0.2, 0.3)))
+        policy = int(rng.choice([T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO]))
+        try:
+            renderer.update_instances(ids, xfs, policy)
+        except engine.HrtError:
+            if policy != T.REBUILD_FORCE_REFIT:
+                raise
+            renderer.update_instances(ids, xfs, T.REBUILD_FORCE_REBUILD)     # a tree that cannot be refitted says so; rebuild instead
+        for i, m in zip(ids, xfs):
+            so.set_instance_transform(i, m)
+        nodes, idx, inst = U._download(renderer)
+        if inst.tobytes() != so.arrays()["instances"].tobytes():
+            failures.append((seed, "instance records")); continue
+        desc = U._desc_with_tlas(so.desc(), nodes, idx, inst)
+        cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                            extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+        po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=fr["frame"], rng_lock_noise=fr["lock"])
+        ref, oo = T.alloc_outputs(fr["w"], fr["h"])
+        ost = orc.render_frame(desc, po_, oo, None)
+        pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=fr["frame"], rng_lock_noise=fr["lock"])
+        for fl in (0, FORCED[case % len(FORCED)]):
+            renderer.reset_history()
+            got, og = T.alloc_outputs(fr["w"], fr["h"])
+            st = renderer.render_params(pg_, og, flags=fl)
+            bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+            bad = {k: v for k, v in bad.items() if v}
+            if not bad and (fl & T.FLAG_COUNTERS) and st.k[1].as_dict() != ost.k[1].as_dict():
+                bad = {"counters": 1}
+            if bad:
+                failures.append((seed, fl, policy, bad)); break
+        if len(failures) >= 5:
+            break
+    assert not failures, "cases that differ from the oracle: %s" % failures
