@@ -228,3 +228,73 @@ def test_random_moves_through_the_device_update_path(orc, renderer):
         if len(failures) >= 5:
             break
     assert not failures, "cases that differ from the oracle: %s" % failures
+
+
+@pytest.mark.timeout(1800)
+def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer):
+    """Random scenes, then a random range of spheres moved / resized / recoloured (hrt_scene_update_spheres) or a random range of mesh
+    vertices displaced (hrt_scene_update_positions) under a random policy: the device's BLAS boxes and instance bounds must be the
+    numpy refit's, and the frame the oracle's frame over the arrays the device now holds."""
+    from tests import test_bvh_update_gpu as U
+    n_cases = max(8, N_CASES // 4)
+    failures = []
+    for case in range(n_cases):
+        seed = SEED0 + 0x300000 + case
+        ops, fr = _scene_recipe(seed)
+        rng = np.random.default_rng(seed ^ 0x13579B)
+        s = engine.Scene(); _apply(s, ops)
+        renderer.commit(s)
+        arrs = s.arrays()
+        policy = int(rng.choice([T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO]))
+        n_pos, n_sph = len(arrs["meshPositions"]), len(arrs["spheres"])
+        what = "positions" if (n_pos > 0 and rng.random() < 0.5) else "spheres"
+        try:
+            if what == "spheres":
+                first = int(rng.integers(0, n_sph)); cnt = int(rng.integers(1, n_sph - first + 1))
+                sp = arrs["spheres"].copy()
+                for f_ in "XYZ":
+                    sp["center"][f_][first:first + cnt] += rng.uniform(-0.4, 0.4, cnt).astype(np.float32)
+                sp["radius"][first:first + cnt] *= rng.uniform(0.6, 1.3, cnt).astype(np.float32)
+                sp["albedo"]["Y"][first:first + cnt] = rng.uniform(0.1, 0.9, cnt).astype(np.float32)
+                renderer.update_spheres(first, sp[first:first + cnt], policy)
+                arrs["spheres"] = sp
+                want_blas, want_inst = U._refit_sphere_blas_numpy(arrs)
+            else:
+                first = int(rng.integers(0, n_pos)); cnt = int(rng.integers(1, n_pos - first + 1))
+                pos = np.stack([arrs["meshPositions"][f_] for f_ in "XYZ"], axis=1)
+                pos[first:first + cnt] += rng.uniform(-0.15, 0.15, (cnt, 3)).astype(np.float32)
+                renderer.update_positions(first, pos[first:first + cnt], policy)
+                for k_, f_ in enumerate("XYZ"):
+                    arrs["meshPositions"][f_] = pos[:, k_]
+                want_blas, want_inst = U._refit_blas_numpy(arrs)
+        except engine.HrtError as e:
+            if "cannot be refitted" in str(e) or "INVALID_STATE" in str(e) or "refit" in str(e):
+                continue                                     # the library says when a BLAS layout is not one it maintains
+            raise
+        got_blas = renderer.download_array("blasNodes")
+        nodes, idx, inst = U._download(renderer)
+        if policy == T.REBUILD_FORCE_REFIT and (got_blas.tobytes() != want_blas.tobytes() or inst.tobytes() != want_inst.tobytes()):
+            failures.append((seed, what, policy, "device BLAS / instance bounds differ from the numpy refit")); continue
+        # (under the other policies the device may have given a BLAS a new topology: the frame is checked over what it holds now)
+        arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = got_blas, inst, nodes, idx
+        arrs["triPrimIdx"], arrs["spherePrimIdx"] = renderer.download_array("triPrimIdx"), renderer.download_array("spherePrimIdx")
+        desc, keep = T.scene_desc_from_arrays(arrs)
+        cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                            extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+        po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=fr["frame"], rng_lock_noise=fr["lock"])
+        ref, oo = T.alloc_outputs(fr["w"], fr["h"])
+        ost = orc.render_frame(desc, po_, oo, None)
+        pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=fr["frame"], rng_lock_noise=fr["lock"])
+        for fl in (0, FORCED[case % len(FORCED)]):
+            renderer.reset_history()
+            got, og = T.alloc_outputs(fr["w"], fr["h"])
+            st = renderer.render_params(pg_, og, flags=fl)
+            bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+            bad = {k: v for k, v in bad.items() if v}
+            if not bad and (fl & T.FLAG_COUNTERS) and st.k[1].as_dict() != ost.k[1].as_dict():
+                bad = {"counters": 1}
+            if bad:
+                failures.append((seed, what, fl, policy, bad)); break
+        if len(failures) >= 5:
+            break
+    assert not failures, "cases that differ: %s" % failures
