@@ -298,3 +298,53 @@ def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer):
         if len(failures) >= 5:
             break
     assert not failures, "cases that differ: %s" % failures
+
+
+@pytest.mark.timeout(1800)
+def test_random_scenes_over_several_device_slots(orc, hrt_lib):
+    """The same random scenes through ONE context over 2, 3 or 5 device slots (row strips dealt round-robin, per-slot gather, tile
+    exchange under reuse), frame sizes with ragged and missing strips: the assembled frame is the oracle's."""
+    n_cases = max(6, N_CASES // 6)
+    multi = {n: engine.RTRenderer([0] * n) for n in (2, 3, 5)}
+    failures = []
+    try:
+        for case in range(n_cases):
+            seed = SEED0 + 0x400000 + case
+            ops, fr = _scene_recipe(seed)
+            rng = np.random.default_rng(seed ^ 0x2468AC)
+            n = int(rng.choice([2, 3, 5]))
+            r = multi[n]
+            w, h = int(rng.choice([24, 40, 57])), int(rng.choice([5, 8, 13, 24, 33, 47]))
+            so = orc.OrcScene(); _apply(so, ops)
+            s = engine.Scene(); _apply(s, ops)
+            r.commit(s); r.reset_history()
+            cfg = scenes.Config("fz", w, h, fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                                extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+            fl = int(rng.choice([0, T.FLAG_STREAMED, T.FLAG_MEGAKERNEL, T.FLAG_COUNTERS]))
+            A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+            for f in range(2 if fr["reuse"] else 1):
+                frame = fr["frame"] + f
+                po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+                pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+                prev, cur = (B, A) if (frame & 1) == 0 else (A, B)
+                ref, oo = T.alloc_outputs(w, h)
+                for k, a in cur.items():
+                    ref[k] = a; setattr(oo, k, a.ctypes.data)
+                po = T.Outputs()
+                for k, a in prev.items():
+                    setattr(po, k, a.ctypes.data)
+                ost = orc.render_frame(so.desc(), po_, oo, po)
+                got, og = T.alloc_outputs(w, h)
+                st = r.render_params(pg_, og, flags=fl)
+                bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+                bad = {k: v for k, v in bad.items() if v}
+                if not bad and (fl & T.FLAG_COUNTERS) and any(st.k[i].as_dict() != ost.k[i].as_dict() for i in range(2)):
+                    bad = {"counters": 1}
+                if bad:
+                    failures.append((seed, n, w, h, fl, f, bad)); break
+            if len(failures) >= 5:
+                break
+    finally:
+        for r in multi.values():
+            r.close()
+    assert not failures, "cases that differ from the oracle (seed, slots, w, h, flags, frame, {array: elements}): %s" % failures
