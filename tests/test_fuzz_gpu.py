@@ -93,6 +93,9 @@ def test_random_scenes_match_the_oracle(orc, renderer):
         w, h = fr["w"], fr["h"]
         for fl in (0, FORCED[case % len(FORCED)]):
             renderer.reset_history()
+            # every third streamed case runs in sample batches: a workspace of one, or one and a half, samples' paths
+            batches = (fl & T.FLAG_STREAMED) and fr["spp"] > 1 and case % 3 == 0
+            renderer.set_workspace_limit((w * h * (2 if case % 2 else 3)) // 2 + 7 if batches else 0)
             A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
             for f in range(2 if fr["reuse"] else 1):
                 frame = fr["frame"] + f
@@ -115,6 +118,7 @@ def test_random_scenes_match_the_oracle(orc, renderer):
                 if bad:
                     failures.append((seed, fl, f, bad))
                     break
+        renderer.set_workspace_limit(0)
         if len(failures) >= 5:
             break
     assert not failures, "cases that differ from the oracle (seed, flags, frame, {array: elements}): %s" % failures
