@@ -133,6 +133,13 @@ def cpu_baseline(cfg_id, cfg, budget_s):
 
 
 # ------------------------------------------------------------------ PMC counters of the timed kernels
+def pmc_child_frames(cfg_id):
+    """Production frames `bench.py --pmc-child` renders (what its per-kernel counter sums are divided by)."""
+    from ilgpu_raytracing_amd import scenes
+    cfg = scenes.CONFIGS[cfg_id]
+    return 1 + (3 if cfg.spp * cfg.width <= 16 * 1920 else 1)
+
+
 def pmc_child(cfg_id, spp):
     """The program the rocprofv3 passes run: the same production frames as the timed region (no torch, no counting frame)."""
     from ilgpu_raytracing_amd import _types as T, engine, scenes
@@ -142,7 +149,7 @@ def pmc_child(cfg_id, spp):
     scenes.build(cfg_id, s)
     r.commit(s)
     p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction, spp=spp or None)
-    for _ in range(1 + (3 if cfg.spp * cfg.width <= 16 * 1920 else 1)):
+    for _ in range(pmc_child_frames(cfg_id)):
         r.render_params(p, None, flags=T.FLAG_NO_SYNC)
     r.synchronize()
     r.close()
@@ -182,7 +189,7 @@ def measure_pmc(cfg_id, spp, out_dir, timeout_s=240):
                     disp[k] += 1
         if rows == 0:
             return None
-    frames = max([n for k, n in disp.items() if "primary" in k] or [1])
+    frames = pmc_child_frames(cfg_id)              # (not counted from dispatches: a frame of the fused kernel can be one launch or two)
     kernels = {}
     for k, cs in per.items():
         kernels[k] = {c: v / frames for c, v in cs.items()}
