@@ -352,3 +352,93 @@ def test_random_scenes_over_several_device_slots(orc, hrt_lib):
         for r in multi.values():
             r.close()
     assert not failures, "cases that differ from the oracle (seed, slots, w, h, flags, frame, {array: elements}): %s" % failures
+
+
+@pytest.mark.timeout(1800)
+def test_random_call_sequences(orc, hrt_lib):
+    """Random SEQUENCES of calls on one renderer -- commit another scene, resize, synchronous frames with outputs in any kernel
+    organisation, runs of asynchronous frames, instance moves on the device, history resets, workspace limits -- with ReSTIR reuse on
+    for most frames, so that every frame depends on the reservoirs every earlier call left behind.  The oracle keeps the same two
+    reservoir sets (ping-pong by frame parity, kept across commits and across resizes to the same pixel count, zeroed by a reset or a new length)."""
+    from tests import test_bvh_update_gpu as U
+    n_seq = max(4, N_CASES // 10)
+    failures = []
+    for seq in range(n_seq):
+        rng = np.random.default_rng(SEED0 + 0x500000 + seq)
+        r = engine.RTRenderer([0])
+        try:
+            w = h = 0
+            so = desc = None
+            A = B = None
+            frame = int(rng.integers(0, 50))
+            log = []
+            for step in range(int(rng.integers(8, 20))):
+                op = rng.choice(["commit", "frame", "frame", "frame", "async", "move", "reset", "limit", "resize"]) if so is not None else "commit"
+                log.append(str(op))
+                if op == "commit":
+                    ops, fr = _scene_recipe(int(rng.integers(0, 2 ** 31)))
+                    so = orc.OrcScene(); _apply(so, ops)
+                    s = engine.Scene(); _apply(s, ops)
+                    r.commit(s); desc = so.desc()
+                    cfg_fr = fr
+                    if w == 0: w, h = fr["w"], fr["h"]
+                elif op == "resize":
+                    w, h = int(rng.choice([24, 32, 48])), int(rng.choice([16, 24, 40]))       # takes effect at the next frame
+                    log[-1] += " %dx%d" % (w, h)
+                elif op == "reset":
+                    r.reset_history()
+                    if A is not None: A, B = H.new_reservoirs(len(A["res_m"]), 1), H.new_reservoirs(len(A["res_m"]), 1)
+                elif op == "limit":
+                    r.set_workspace_limit(int(rng.choice([0, w * h + 3, 2 * w * h + 1, 10 ** 9])))
+                elif op == "move":
+                    n_inst = len(so.arrays()["instances"])
+                    ids = sorted(set(int(v) for v in rng.integers(0, n_inst, int(rng.integers(1, min(n_inst, 4) + 1)))))
+                    xfs = [scenes.rotation_affine(str(rng.choice(list("xyz"))), float(rng.uniform(-60, 60)), float(rng.choice([0.7, 1.0, 1.0])), tuple(float(v) for v in rng.uniform(-0.5, 0.5, 3))) for _ in ids]
+                    r.update_instances(ids, xfs, int(rng.choice([T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO])))
+                    for i, m in zip(ids, xfs):
+                        so.set_instance_transform(i, m)
+                    nodes, idx, inst = U._download(r)
+                    keep = (nodes, idx, inst)
+                    desc = U._desc_with_tlas(so.desc(), nodes, idx, inst)
+                else:
+                    fr = cfg_fr
+                    n_frames = 1 if op == "frame" else int(rng.integers(2, 5))
+                    reuse = bool(rng.random() < 0.75)
+                    fl = int(rng.choice([0, 0, T.FLAG_MEGAKERNEL, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_REFERENCE_LAYOUT, T.FLAG_COUNTERS]))
+                    spp = int(rng.integers(1, 4))
+                    cfg = scenes.Config("sq", w, h, spp, fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                                        extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+                    if A is None or len(A["res_m"]) != w * h:
+                        # EnsureLength reallocates (and this library zeroes) on another LENGTH only (Framebuffer.cs:60-66): a frame of 48x16
+                        # after one of 32x24 keeps every array, stale history included
+                        A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+                    for j in range(n_frames):
+                        frame += int(rng.integers(1, 3))
+                        last = j == n_frames - 1
+                        po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=frame, reuse=reuse, rng_lock_noise=fr["lock"])
+                        pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=frame, reuse=reuse, rng_lock_noise=fr["lock"])
+                        prev, cur = (B, A) if (frame & 1) == 0 else (A, B)
+                        ref, oo = T.alloc_outputs(w, h)
+                        for k, a in cur.items():
+                            ref[k] = a; setattr(oo, k, a.ctypes.data)
+                        po = T.Outputs()
+                        for k, a in prev.items():
+                            setattr(po, k, a.ctypes.data)
+                        orc.render_frame(desc, po_, oo, po)
+                        if op == "async" and not last:
+                            r.render_params(pg_, None, flags=(fl & ~T.FLAG_COUNTERS) | T.FLAG_NO_SYNC)
+                            continue
+                        got, og = T.alloc_outputs(w, h)
+                        r.render_params(pg_, og, flags=fl)
+                        bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+                        bad = {k: v for k, v in bad.items() if v}
+                        if bad:
+                            failures.append((seq, step, log[-6:], fl, reuse, bad)); break
+                    log[-1] += " x%d fl%d reuse%d" % (n_frames, fl, reuse)
+                if failures and failures[-1][0] == seq:
+                    break
+        finally:
+            r.close()
+        if len(failures) >= 4:
+            break
+    assert not failures, "sequences that diverge from the oracle (sequence, step, last calls, flags, reuse, {array: elements}): %s" % failures
