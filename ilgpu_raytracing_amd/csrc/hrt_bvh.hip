@@ -32,8 +32,15 @@ HRT_D F3 xf_vector(const hrt_affine3x4& m, F3 v)
 {
     return mk3(m.m00 * v.x + m.m01 * v.y + m.m02 * v.z, m.m10 * v.x + m.m11 * v.y + m.m12 * v.z, m.m20 * v.x + m.m21 * v.y + m.m22 * v.z);
 }
-HRT_D F3 min3(F3 a, F3 b) { return mk3(hrt_fmin(a.x, b.x), hrt_fmin(a.y, b.y), hrt_fmin(a.z, b.z)); }
-HRT_D F3 max3(F3 a, F3 b) { return mk3(hrt_fmax(a.x, b.x), hrt_fmax(a.y, b.y), hrt_fmax(a.z, b.z)); }
+// These kernels stand in for HOST code of the reference (the builders of Scene.cs), so their Min / Max are .NET's Math.Min /
+// Max -- a NaN operand is returned -- and not the v_min_f32 / v_max_f32 the render kernels use (include/hrt_math.h).
+HRT_D F3 min3(F3 a, F3 b) { return mk3(hrt_host_fmin(a.x, b.x), hrt_host_fmin(a.y, b.y), hrt_host_fmin(a.z, b.z)); }
+HRT_D F3 max3(F3 a, F3 b) { return mk3(hrt_host_fmax(a.x, b.x), hrt_host_fmax(a.y, b.y), hrt_host_fmax(a.z, b.z)); }
+HRT_D F3 host_normalize(F3 v)
+{
+    const float inv = hrt_rsqrt(hrt_host_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z));
+    return mk3(v.x * inv, v.y * inv, v.z * inv);
+}
 HRT_D bool is_identity(const hrt_affine3x4& m)
 {
     return m.m00 == 1.f && m.m01 == 0.f && m.m02 == 0.f && m.m03 == 0.f && m.m10 == 0.f && m.m11 == 1.f && m.m12 == 0.f && m.m13 == 0.f &&
@@ -68,7 +75,7 @@ __global__ void __launch_bounds__(kBlock) k_set_transforms(TlasDevice T, const i
                 sz = hrt_sqrt(c2.x * c2.x + c2.y * c2.y + c2.z * c2.z);
     const float uni = (sx + sy + sz) / 3.f;
     const float inv = uni > 0.f ? 1.f / uni : 1.f;
-    const F3 r0 = normalize(c0), r1 = normalize(c1), r2 = normalize(c2);
+    const F3 r0 = host_normalize(c0), r1 = host_normalize(c1), r2 = host_normalize(c2);
     hrt_affine3x4 im;
     im.m00 = r0.x * inv; im.m01 = r1.x * inv; im.m02 = r2.x * inv; im.m03 = 0.f;
     im.m10 = r0.y * inv; im.m11 = r1.y * inv; im.m12 = r2.y * inv; im.m13 = 0.f;
@@ -115,6 +122,10 @@ __global__ void __launch_bounds__(kBlock) k_leaf_slots(TlasDevice T)
         f.c = make_float4(i2f(in.blasRoot), i2f(in.blasRoot + in.blasNodeCount), scale, 0.f);
         atomicOr(T.flags, 1);
     }
+    // A box with a NaN bound or with min > max: the union over it (k_refit, host Min / Max) need not contain, as far as the slab
+    // test goes, the other boxes it unites -- the walks that skip inner-node tests must not run over such a tree.
+    if (!(in.worldBoundsMin.X <= in.worldBoundsMax.X && in.worldBoundsMin.Y <= in.worldBoundsMax.Y && in.worldBoundsMin.Z <= in.worldBoundsMax.Z))
+        atomicOr(T.flags + 1, 1);
     T.finst[i] = f;
 }
 

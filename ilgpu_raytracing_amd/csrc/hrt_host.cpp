@@ -40,11 +40,12 @@ inline hrt_float3 f3(V3 v) { hrt_float3 r = {v.x, v.y, v.z}; return r; }
 inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
-inline V3 vmin(V3 a, V3 b) { return v3(hrt_fmin(a.x, b.x), hrt_fmin(a.y, b.y), hrt_fmin(a.z, b.z)); }
-inline V3 vmax(V3 a, V3 b) { return v3(hrt_fmax(a.x, b.x), hrt_fmax(a.y, b.y), hrt_fmax(a.z, b.z)); }
+// Host code of the reference: Min / Max are .NET's Math.Min / Max (a NaN operand is returned), not the kernels' minNum.
+inline V3 vmin(V3 a, V3 b) { return v3(hrt_host_fmin(a.x, b.x), hrt_host_fmin(a.y, b.y), hrt_host_fmin(a.z, b.z)); }
+inline V3 vmax(V3 a, V3 b) { return v3(hrt_host_fmax(a.x, b.x), hrt_host_fmax(a.y, b.y), hrt_host_fmax(a.z, b.z)); }
 inline float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline V3 vcross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-inline V3 vnorm(V3 v) { float inv = hrt_rsqrt(hrt_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z)); return v3(v.x * inv, v.y * inv, v.z * inv); }
+inline V3 vnorm(V3 v) { float inv = hrt_rsqrt(hrt_host_fmax(1e-20f, v.x * v.x + v.y * v.y + v.z * v.z)); return v3(v.x * inv, v.y * inv, v.z * inv); }
 inline float vlen(V3 v) { return hrt_sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
 inline V3 xpoint(const hrt_affine3x4& m, V3 p)
 {

@@ -739,7 +739,10 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         for (int64_t ii = 0; once && ii < nI; ii++) if (!seen[(size_t)ii]) once = false;
         out.inst_once = once;
         auto inside = [](const NodeQ& c, const NodeQ& p) {
-            return c.lo.x >= p.lo.x && c.lo.y >= p.lo.y && c.lo.z >= p.lo.z && c.hi.x <= p.hi.x && c.hi.y <= p.hi.y && c.hi.z <= p.hi.z;      // false with a NaN
+            // false with a NaN.  The child has to be a regular box (min <= max) too: the slab test reads an inverted box as its
+            // mirror image, which these comparisons say nothing about
+            return c.lo.x <= c.hi.x && c.lo.y <= c.hi.y && c.lo.z <= c.hi.z &&
+                   c.lo.x >= p.lo.x && c.lo.y >= p.lo.y && c.lo.z >= p.lo.z && c.hi.x <= p.hi.x && c.hi.y <= p.hi.y && c.hi.z <= p.hi.z;
         };
         for (size_t i = 1; i < (size_t)nT; i++)
             if ((reachableT < 0 || (int32_t)i < reachableT) && out.parent[i] >= 0 && !inside(out.tlas[i], out.tlas[(size_t)out.parent[i]])) out.nested = false;
@@ -877,8 +880,11 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             f.c = mkf4(bits_f(in.blasRoot), bits_f(in.blasRoot + in.blasNodeCount), scale, 0.f);
         }
         out.finst[(size_t)i] = f;
-        if (fast && !(f.a.x >= in.worldBoundsMin.X && f.a.y >= in.worldBoundsMin.Y && f.a.z >= in.worldBoundsMin.Z &&
-                      f.b.x <= in.worldBoundsMax.X && f.b.y <= in.worldBoundsMax.Y && f.b.z <= in.worldBoundsMax.Z)) out.own_in_world = false;
+        // BOTH corners of the own box: a negative radius inverts it (max < min), and the slab test reads that as the mirror image
+        auto within = [](float v, float lo, float hi) { return v >= lo && v <= hi; };      // false with a NaN
+        if (fast && !(within(f.a.x, in.worldBoundsMin.X, in.worldBoundsMax.X) && within(f.b.x, in.worldBoundsMin.X, in.worldBoundsMax.X) &&
+                      within(f.a.y, in.worldBoundsMin.Y, in.worldBoundsMax.Y) && within(f.b.y, in.worldBoundsMin.Y, in.worldBoundsMax.Y) &&
+                      within(f.a.z, in.worldBoundsMin.Z, in.worldBoundsMax.Z) && within(f.b.z, in.worldBoundsMin.Z, in.worldBoundsMax.Z))) out.own_in_world = false;
     }
     out.ftri.resize((size_t)std::max<int64_t>(nTP, 1));
     std::memset(out.ftri.data(), 0, out.ftri.size() * sizeof(FTri));
@@ -1025,7 +1031,10 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
             if ((int64_t)first + j < 0 || (int64_t)first + j >= nTI) { out.nested = false; break; }
             const FInst& f = out.finst[(size_t)(first + j)];
             if (!(__builtin_bit_cast(int, f.a.w) & FI_FAST_SPHERE)) continue;
-            if (!(f.a.x >= q.lo.x && f.a.y >= q.lo.y && f.a.z >= q.lo.z && f.b.x <= q.hi.x && f.b.y <= q.hi.y && f.b.z <= q.hi.z)) { out.nested = false; break; }
+            // both corners of the own box (a negative radius inverts it, and the slab test reads that as the mirror image)
+            auto within = [](float v, float lo, float hi) { return v >= lo && v <= hi; };
+            if (!(within(f.a.x, q.lo.x, q.hi.x) && within(f.b.x, q.lo.x, q.hi.x) && within(f.a.y, q.lo.y, q.hi.y) && within(f.b.y, q.lo.y, q.hi.y) &&
+                  within(f.a.z, q.lo.z, q.hi.z) && within(f.b.z, q.lo.z, q.hi.z))) { out.nested = false; break; }
         }
     }
     if (!out.nested) out.inst_once = false;
@@ -1732,7 +1741,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     int flags[4] = {1, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(flags, T.flags, sizeof(flags), hipMemcpyDeviceToHost, d.stream));
     HIPCHK(c, hipStreamSynchronize(d.stream));
-    if (flags[0] != 0 || leaves <= 0 || (int64_t)T.nT + T.nTI >= kEnd) return HRT_OK;      // an instance that is not a fast sphere after all
+    if (flags[0] != 0 || flags[1] != 0 || leaves <= 0 || (int64_t)T.nT + T.nTI >= kEnd) return HRT_OK;      // an instance that is not a fast sphere after all
     // leaf slot of the uploaded tree -> leaf slot of this one (both list every instance once)
     if (T.nTI != (int)nSlots) return HRT_OK;
     std::vector<int32_t> mine((size_t)nSlots), slotOfInst((size_t)c->n_inst, -1), map((size_t)nSlots);
@@ -1852,7 +1861,8 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             c->packed_feat = c->feat_alpha ? 3 : (general ? 1 : 0);
             // the leaf sweep skips box tests the reference makes, which is only sound over nested boxes: the device's trees are unions of
             // the instances' worldBounds, so it takes every fast-sphere instance's own box to lie inside its worldBounds
-            c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->own_in_world && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
+            // ... and every worldBounds to be a regular box (no NaN bound, min <= max: h_flags[1]), or the unions are not nested
+            c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->own_in_world && h_flags[1] == 0 && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
             c->n_tlas = T.nT; c->n_slots = T.nTI;
             c->small_scene = (c->n_tlas + c->n_blas) <= kSmallSceneNodes;
             c->wide_depth = 0;                       // the 4-wide collapse is not maintained on the device

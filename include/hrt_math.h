@@ -67,6 +67,24 @@ HRT_HD float hrt_fmax(float a, float b)
     return (a != a) ? b : a;
 #endif
 }
+/* The scene BUILDERS of the reference run on the host, where XMath.Min / Max are .NET's Math.Min / Max: IEEE 754-2019
+ * minimum / maximum -- a NaN operand is returned (the first one when both are), and -0 orders below +0.  They differ from
+ * the kernels' minNum only when an operand is NaN.  Everything that restates or emulates builder code (Scene.cs, Camera.cs)
+ * uses these; the kernels never do. */
+HRT_HD float hrt_host_fmin(float a, float b)
+{
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a == b) return hrt_u2f(hrt_f2u(a) | hrt_f2u(b));
+    return a < b ? a : b;
+}
+HRT_HD float hrt_host_fmax(float a, float b)
+{
+    if (a != a) return a;
+    if (b != b) return b;
+    if (a == b) return hrt_u2f(hrt_f2u(a) & hrt_f2u(b));
+    return a > b ? a : b;
+}
 HRT_HD int hrt_imin(int a, int b) { return a < b ? a : b; }
 HRT_HD int hrt_imax(int a, int b) { return a > b ? a : b; }
 /* XMath.Clamp(v, lo, hi) = Max(Min(v, hi), lo) */

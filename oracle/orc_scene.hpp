@@ -28,6 +28,18 @@
 
 namespace orc {
 
+// ------------------------------------------------------------------ host flavour of Float3.Min / Max / Normalize
+// Everything in this file is code the reference runs on the HOST, where XMath.Min / Max are Math.Min / Max of .NET (a NaN
+// operand is returned; include/hrt_math.h, hrt_host_fmin).  The kernels' Min / Max / Normalize of orc_kernels.hpp (minNum)
+// are not used here.
+static inline Float3 HMin(Float3 a, Float3 b) { return Float3(hrt_host_fmin(a.X, b.X), hrt_host_fmin(a.Y, b.Y), hrt_host_fmin(a.Z, b.Z)); } // Float3.cs:67-70
+static inline Float3 HMax(Float3 a, Float3 b) { return Float3(hrt_host_fmax(a.X, b.X), hrt_host_fmax(a.Y, b.Y), hrt_host_fmax(a.Z, b.Z)); } // Float3.cs:73-76
+static inline Float3 HNormalize(Float3 v)                                                                                                     // Float3.cs:91-95
+{
+    float inv = hrt_rsqrt(hrt_host_fmax(1e-20f, v.X * v.X + v.Y * v.Y + v.Z * v.Z));
+    return Float3(v.X * inv, v.Y * inv, v.Z * inv);
+}
+
 // ------------------------------------------------------------------ .NET 8 ArraySortHelper<T>
 template <class T, class Cmp>
 struct DotnetSort {
@@ -125,23 +137,23 @@ struct CameraOps {
     // :193-205
     static void OrthoBasis(Float3 forward, Float3 upHint, Float3& u, Float3& v, Float3& w)
     {
-        Float3 f = Normalize(forward);
+        Float3 f = HNormalize(forward);
         Float3 up = upHint;
         if (hrt_abs(Dot(f, up)) > 0.999f)
         {
             up = Float3(0.f, 1.f, 0.f);
             if (hrt_abs(Dot(f, up)) > 0.999f) up = Float3(1.f, 0.f, 0.f);
         }
-        u = Normalize(Cross(f, up));
-        v = Normalize(Cross(u, f));
+        u = HNormalize(Cross(f, up));
+        v = HNormalize(Cross(u, f));
         w = Float3(-f.X, -f.Y, -f.Z);
     }
     // :184-191
     static void UpdateDerived(hrt_camera& c, float aspectIn, float fovYRadIn)
     {
-        Float3 forward = Normalize((Float3(c.lowerLeft) + Float3(c.horizontal) * 0.5f + Float3(c.vertical) * 0.5f) - Float3(c.origin));
-        Float3 up = Normalize(c.vertical);
-        Float3 right = Normalize(Cross(forward, up));
+        Float3 forward = HNormalize((Float3(c.lowerLeft) + Float3(c.horizontal) * 0.5f + Float3(c.vertical) * 0.5f) - Float3(c.origin));
+        Float3 up = HNormalize(c.vertical);
+        Float3 right = HNormalize(Cross(forward, up));
         c.forward = forward; c.up = up; c.right = right;
         c.aspect = aspectIn;
         c.fovYRadians = fovYRadIn;
@@ -158,8 +170,8 @@ struct CameraOps {
         Float3 lookAt(0.f, 0.5f, 0.f);
         Float3 upHint(0.f, 1.f, 0.f);
 
-        Float3 w = Normalize(origin - lookAt);
-        Float3 u = Normalize(Cross(upHint, w));
+        Float3 w = HNormalize(origin - lookAt);
+        Float3 u = HNormalize(Cross(upHint, w));
         Float3 v = Cross(w, u);
 
         Float3 lowerLeft = origin - u * halfWidth - v * halfHeight - w;
@@ -179,7 +191,7 @@ struct CameraOps {
         float halfHeight = hrt_tan(0.5f * theta);
         float halfWidth = aspect * halfHeight;
 
-        Float3 forward = Normalize(lookAt - origin);
+        Float3 forward = HNormalize(lookAt - origin);
         Float3 u, v, w;
         OrthoBasis(forward, up, u, v, w);
 
@@ -189,10 +201,10 @@ struct CameraOps {
         c.vertical = v * (2.f * halfHeight);
         c.lowerLeft = origin - u * halfWidth - v * halfHeight + forward * focusDist;
 
-        Float3 fwd = Normalize((Float3(c.lowerLeft) + Float3(c.horizontal) * 0.5f + Float3(c.vertical) * 0.5f) - origin);
+        Float3 fwd = HNormalize((Float3(c.lowerLeft) + Float3(c.horizontal) * 0.5f + Float3(c.vertical) * 0.5f) - origin);
         c.forward = fwd;
-        c.right = Normalize(Cross(fwd, v));
-        c.up = Normalize(v);
+        c.right = HNormalize(Cross(fwd, v));
+        c.up = HNormalize(v);
         c.aspect = aspect;
         c.fovYRadians = theta;
         return c;
@@ -208,9 +220,9 @@ struct CameraOps {
     static void BakeCameraDerived(hrt_camera& c, int pixelW, int pixelH)
     {
         Float3 center = Float3(c.lowerLeft) + Float3(c.horizontal) * 0.5f + Float3(c.vertical) * 0.5f;
-        Float3 forward = Normalize(center - Float3(c.origin));
-        Float3 up = Normalize(c.vertical);
-        Float3 right = Normalize(Cross(forward, up));
+        Float3 forward = HNormalize(center - Float3(c.origin));
+        Float3 up = HNormalize(c.vertical);
+        Float3 right = HNormalize(Cross(forward, up));
 
         float focusDist = Length(center - Float3(c.origin));
         float halfHeight = 0.5f * Length(c.vertical);
@@ -229,7 +241,7 @@ struct CameraOps {
     // RTRenderer.cs:174-178
     static Float3 SunDir(float azimuth, float elevation)
     {
-        return Normalize(Float3(hrt_cos(azimuth) * hrt_cos(elevation), hrt_sin(elevation), hrt_sin(azimuth) * hrt_cos(elevation)));
+        return HNormalize(Float3(hrt_cos(azimuth) * hrt_cos(elevation), hrt_sin(elevation), hrt_sin(azimuth) * hrt_cos(elevation)));
     }
 };
 
@@ -358,8 +370,8 @@ struct Scene {
         for (int i = 0; i < nIds; i++)
         {
             hrt_sphere s = _hSpheres[sphereIds[i]];
-            bmin = Min(bmin, Float3(s.center.X - s.radius, s.center.Y - s.radius, s.center.Z - s.radius));
-            bmax = Max(bmax, Float3(s.center.X + s.radius, s.center.Y + s.radius, s.center.Z + s.radius));
+            bmin = HMin(bmin, Float3(s.center.X - s.radius, s.center.Y - s.radius, s.center.Z - s.radius));
+            bmax = HMax(bmax, Float3(s.center.X + s.radius, s.center.Y + s.radius, s.center.Z + s.radius));
         }
 
         int primStart = sphereIds[0];
@@ -535,8 +547,8 @@ struct Scene {
     {
         hrt_mesh_tri tri = _hMeshTris[triIndex];
         Float3 v0 = _hMeshPositions[tri.i0], v1 = _hMeshPositions[tri.i1], v2 = _hMeshPositions[tri.i2];
-        mn = Min(v0, Min(v1, v2));
-        mx = Max(v0, Max(v1, v2));
+        mn = HMin(v0, HMin(v1, v2));
+        mx = HMax(v0, HMax(v1, v2));
     }
     Float3 CenterOfTriangle(int triIndex) const
     {
@@ -595,8 +607,8 @@ struct Scene {
         {
             for (int i = start; i < start + count; i++)
             {
-                nbMin = Min(nbMin, bminPre[i]);     // by POSITION, not through idx[] (reference quirk)
-                nbMax = Max(nbMax, bmaxPre[i]);
+                nbMin = HMin(nbMin, bminPre[i]);     // by POSITION, not through idx[] (reference quirk)
+                nbMax = HMax(nbMax, bmaxPre[i]);
             }
         }
         else
@@ -606,8 +618,8 @@ struct Scene {
                 int triIndex = primIdx[idx[i]];
                 Float3 mn, mx;
                 BoundsOfTriangle(triIndex, mn, mx);
-                nbMin = Min(nbMin, mn);
-                nbMax = Max(nbMax, mx);
+                nbMin = HMin(nbMin, mn);
+                nbMax = HMax(nbMax, mx);
             }
         }
 
@@ -657,8 +669,8 @@ struct Scene {
         for (int i = start; i < start + count; i++)
         {
             const hrt_instance& r = inst[idx[i]];
-            nbMin = Min(nbMin, r.worldBoundsMin);
-            nbMax = Max(nbMax, r.worldBoundsMax);
+            nbMin = HMin(nbMin, r.worldBoundsMin);
+            nbMax = HMax(nbMax, r.worldBoundsMax);
         }
         node.boundsMin = nbMin; node.boundsMax = nbMax;
         outNodes.push_back(node);
@@ -707,8 +719,8 @@ struct Scene {
         for (int i = 0; i < 8; i++)
         {
             Float3 w = TransformPoint(m, c[i]);
-            mn = Min(mn, w);
-            mx = Max(mx, w);
+            mn = HMin(mn, w);
+            mx = HMax(mx, w);
         }
         outMin = mn; outMax = mx;
     }
@@ -721,8 +733,8 @@ struct Scene {
         {
             hrt_mesh_tri t = tris[i];
             Float3 v0 = pos[t.i0], v1 = pos[t.i1], v2 = pos[t.i2];
-            bmin = Min(bmin, Min(v0, Min(v1, v2)));
-            bmax = Max(bmax, Max(v0, Max(v1, v2)));
+            bmin = HMin(bmin, HMin(v0, HMin(v1, v2)));
+            bmax = HMax(bmax, HMax(v0, HMax(v1, v2)));
         }
     }
     // :616-638
@@ -734,9 +746,9 @@ struct Scene {
         uniformScale = (sx + sy + sz) / 3.f;
         float inv = uniformScale > 0.f ? 1.f / uniformScale : 1.f;
 
-        Float3 r0 = Normalize(Float3(m.m00, m.m10, m.m20));
-        Float3 r1 = Normalize(Float3(m.m01, m.m11, m.m21));
-        Float3 r2 = Normalize(Float3(m.m02, m.m12, m.m22));
+        Float3 r0 = HNormalize(Float3(m.m00, m.m10, m.m20));
+        Float3 r1 = HNormalize(Float3(m.m01, m.m11, m.m21));
+        Float3 r2 = HNormalize(Float3(m.m02, m.m12, m.m22));
 
         hrt_affine3x4 invM; std::memset(&invM, 0, sizeof(invM));
         invM.m00 = r0.X * inv; invM.m01 = r1.X * inv; invM.m02 = r2.X * inv; invM.m03 = 0.f;

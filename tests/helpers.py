@@ -13,6 +13,21 @@ def bits_equal(a, b):
     return a == b
 
 
+def canon(a):
+    """Copy of a (structured) array with every float NaN replaced by the one canonical quiet NaN, for byte comparisons of records
+    computed on two machines: which NaN an operation returns (payload, sign) is the one thing x86-64 and gfx950 do not agree on."""
+    a = np.array(a, copy=True)
+
+    def fix(v):
+        if v.dtype.names:
+            for f in v.dtype.names:
+                fix(v[f])
+        elif v.dtype.kind == "f":
+            v[np.isnan(v)] = np.float32(np.nan)
+    fix(a)
+    return a
+
+
 def zero_sign_only(a, b):
     """Elements that are equal as floats but not as bit patterns (+0 vs -0): reported separately in failures."""
     if a.dtype != np.float32:
