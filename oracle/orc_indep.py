@@ -560,6 +560,11 @@ def float_to_i16(x):                                                            
     return trunc_int(cl) & 0xFFFF
 
 
+def to_i32(v):
+    v &= U32
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
 def to_byte(x):                                                                     # :72-76
     c = fmin(f32(1), fmax(f32(0), x))
     return trunc_int(f32(255.99) * c)
@@ -628,7 +633,7 @@ def render(arrs, params, math, prev=None, cur=None):
             if not hit:                                                             # StoreMiss :100-108
                 g = (0, add(wray[0], muls(wray[1], f32(1e6))), v3(0, 1, 0), v3(0, 0, 0), -1, -1)
             else:                                                                   # StoreHit :90-98
-                g = (1, add(wray[0], muls(wray[1], t)), n, alb, (shade & 0xFFFF) | (float_to_i16(ior) << 16), obj)
+                g = (1, add(wray[0], muls(wray[1], t)), n, alb, to_i32((shade & 0xFFFF) | (float_to_i16(ior) << 16)), obj)     # (int arithmetic wraps: ior >= 32.768)
             gb.append(g)
             K.gb = gb
             out["gb_hitMask"][index], out["gb_worldPos"][index], out["gb_normalWS"][index] = g[0], g[1], g[2]

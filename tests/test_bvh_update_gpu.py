@@ -365,7 +365,7 @@ def _refit_blas_numpy(arrs):
         n = nodes[i]
         if n["count"] > 0:
             v = pos[tris[prim[n["first"]:n["first"] + n["count"]]].reshape(-1)]
-            lo, hi = v.min(axis=0), v.max(axis=0)
+            lo, hi = np.minimum(v.min(axis=0), FMAX3), np.maximum(v.max(axis=0), -FMAX3)
         else:
             a, b = rec(int(n["left"])), rec(int(n["right"]))
             lo, hi = np.minimum(a[0], b[0]), np.maximum(a[1], b[1])

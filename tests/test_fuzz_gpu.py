@@ -59,6 +59,61 @@ def _scene_recipe(seed):
     return ops, frame
 
 
+NAN, INF = float("nan"), float("inf")
+
+
+def _poison(ops, fr, seed):
+    """The recipe again with non-finite, zero, negative and huge numbers planted where nobody would author them: sphere centres,
+    radii, albedos and IORs, instance scales, angles and translations, single mesh vertices, alpha cutoffs, the camera's field of
+    view, the sun's elevation.  IEEE arithmetic gives every one of them SOME result in the reference; the bits have to be the same.
+    One NaN or infinity in a box reaches the TLAS root through the host's Min / Max and hides the whole scene (every slab test
+    fails), so two scenes in three get their GEOMETRY poisoned with finite numbers only (zero, negative, huge, tiny), and the rest
+    with anything; what does not feed a box (albedo, IOR, shading id, alpha cutoff) is poisoned with anything in every scene."""
+    rng = np.random.default_rng(seed ^ 0xBAD5EED)
+    pick = lambda pool: float(pool[int(rng.integers(0, len(pool)))])
+    wild = rng.random() < 0.33
+    coord = [NAN, INF, -INF, 1e30, -1e30] if wild else [1e30, -1e30, 1e18, 0.0, 3e-39]
+    radius = lambda r: pick([0.0, -r, INF, NAN, 1e-30, 1e30, -INF] if wild else [0.0, -r, -3.0 * r, 1e-30, 3e-39, 1e30, 50.0])
+    scale = [0.0, -1.0, -0.5, 1e19, 1e-19, NAN, INF] if wild else [0.0, -1.0, -0.5, 1e19, 1e-19, 3.0]
+    one_of3 = lambda v, pool: tuple(pick(pool) if i == int(rng.integers(0, 3)) else x for i, x in enumerate(v))
+    def xf_poison(xf):
+        if xf is None or rng.random() >= 0.2: return xf
+        axis, ang, sc, tr = xf
+        k = int(rng.integers(0, 3))
+        if k == 0: sc = pick(scale)
+        elif k == 1: ang = pick([1e9, -720.0, 1e30, 90.0])
+        else: tr = one_of3(tr, coord)
+        return (axis, ang, sc, tr)
+    out = []
+    for op in ops:
+        if op[0] == "sphere":
+            _, c, r, kd, sh, ior, own = op
+            if rng.random() < 0.07: c = one_of3(c, coord)
+            if rng.random() < 0.08: r = radius(r)
+            if rng.random() < 0.1: kd = one_of3(kd, [NAN, INF, -1.0, 0.0, 1e30])
+            if rng.random() < 0.1: ior = pick([NAN, 0.0, INF, -1.5, 1.0, 1e-30, 40.0])
+            if rng.random() < 0.05: sh = int(rng.choice([-1, 3, 7, 2 ** 31 - 1]))
+            out.append(("sphere", c, r, kd, sh, ior, own))
+        elif op[0] == "instance":
+            out.append(("instance", op[1], xf_poison(op[2])))
+        else:
+            _, xq, yq, zq, uvs, mat, tex, mask, xf = op
+            if rng.random() < 0.3:
+                zq = zq.copy()
+                zq.flat[int(rng.integers(0, zq.size))] = pick(coord)
+            if rng.random() < 0.15:
+                xq = xq.copy()
+                xq.flat[int(rng.integers(0, xq.size))] = pick(coord)                    # texture coordinates derive from xq too
+            if rng.random() < 0.3:
+                mat = dict(mat); mat["alpha_cutoff"] = pick([NAN, 2.0, -1.0, INF, 0.0, 1.0])
+            out.append(("mesh", xq, yq, zq, uvs, mat, tex, mask, xf_poison(xf)))
+    fr = dict(fr)
+    if rng.random() < 0.08: fr["vfov"] = pick([0.0, 179.9999, 180.0, 360.0, -60.0])
+    if rng.random() < 0.08: fr["sun"] = (fr["sun"][0], pick([INF, NAN, 0.0, -1.0, 1.5707964]))
+    if rng.random() < 0.04: fr["origin"] = tuple(pick([1e30, INF]) if i == 1 else v for i, v in enumerate(fr["origin"]))
+    return out, fr
+
+
 def _apply(b, ops):
     ids = []
     for op in ops:
@@ -79,14 +134,18 @@ def _apply(b, ops):
 
 
 @pytest.mark.timeout(1800)
-def test_random_scenes_match_the_oracle(orc, renderer):
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_scenes_match_the_oracle(orc, renderer, hostile):
     failures = []
-    for case in range(N_CASES):
-        seed = SEED0 + case
+    for case in range(N_CASES if not hostile else max(8, N_CASES // 2)):
+        seed = SEED0 + case + (0x700000 if hostile else 0)
         ops, fr = _scene_recipe(seed)
+        if hostile:
+            ops, fr = _poison(ops, fr, seed)
         so = orc.OrcScene(); _apply(so, ops)
         s = engine.Scene(); _apply(s, ops)
-        assert so.arrays()["instances"].tobytes() == s.arrays()["instances"].tobytes()
+        for k_, a_ in so.arrays().items():
+            assert H.canon(a_).tobytes() == H.canon(s.arrays()[k_]).tobytes(), (seed, k_)
         renderer.commit(s)
         cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
                             extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
@@ -176,7 +235,8 @@ def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer):
 
 
 @pytest.mark.timeout(1800)
-def test_random_moves_through_the_device_update_path(orc, renderer):
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_moves_through_the_device_update_path(orc, renderer, hostile):
     """Random scenes, then random instance moves (rigid, scaled, identity, a degenerate one now and then) under a random policy
     (refit / rebuild / auto) on the device: the instance records must be the oracle's, and the frame must be the oracle's frame on
     the tree the device made (downloaded)."""
@@ -184,9 +244,11 @@ def test_random_moves_through_the_device_update_path(orc, renderer):
     n_cases = max(8, N_CASES // 4)
     failures = []
     for case in range(n_cases):
-        seed = SEED0 + 0x200000 + case
+        seed = SEED0 + 0x200000 + case + (0x40000 if hostile else 0)
         ops, fr = _scene_recipe(seed)
         rng = np.random.default_rng(seed ^ 0xABCDEF)
+        if hostile and rng.random() < 0.5:
+            ops, fr = _poison(ops, fr, seed)
         so = orc.OrcScene(); _apply(so, ops)
         s = engine.Scene(); _apply(s, ops)
         renderer.commit(s)
@@ -200,6 +262,9 @@ def test_random_moves_through_the_device_update_path(orc, renderer):
             if k < 0.15: xfs.append(T.identity_affine())
             elif k < 0.9: xfs.append(scenes.rotation_affine(str(rng.choice(list("xyz"))), float(rng.uniform(-90, 90)), float(rng.choice([0.5, 0.8, 1.0, 1.0, 1.25])), tuple(float(v) for v in rng.uniform(-0.8, 0.8, 3))))
             else: xfs.append(scenes.rotation_affine("y", 10.0, float(rng.choice([0.0, -1.0, 1e10])), (0.1, 0.2, 0.3)))
+            if hostile and rng.random() < 0.3:      # one matrix entry replaced: a shear, a zero column, now and then a NaN / infinity
+                m = xfs[-1]
+                setattr(m, "m%d%d" % (int(rng.integers(0, 3)), int(rng.integers(0, 4))), float(rng.choice([0.0, 0.7, -2.5, 1e19, 1e-30] + ([NAN, INF] if rng.random() < 0.3 else []))))
         policy = int(rng.choice([T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO]))
         try:
             renderer.update_instances(ids, xfs, policy)
@@ -210,7 +275,7 @@ def test_random_moves_through_the_device_update_path(orc, renderer):
         for i, m in zip(ids, xfs):
             so.set_instance_transform(i, m)
         nodes, idx, inst = U._download(renderer)
-        if inst.tobytes() != so.arrays()["instances"].tobytes():
+        if H.canon(inst).tobytes() != H.canon(so.arrays()["instances"]).tobytes():
             failures.append((seed, "instance records")); continue
         desc = U._desc_with_tlas(so.desc(), nodes, idx, inst)
         cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
@@ -235,7 +300,8 @@ def test_random_moves_through_the_device_update_path(orc, renderer):
 
 
 @pytest.mark.timeout(1800)
-def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer):
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer, hostile):
     """Random scenes, then a random range of spheres moved / resized / recoloured (hrt_scene_update_spheres) or a random range of mesh
     vertices displaced (hrt_scene_update_positions) under a random policy: the device's BLAS boxes and instance bounds must be the
     numpy refit's, and the frame the oracle's frame over the arrays the device now holds."""
@@ -243,9 +309,12 @@ def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer):
     n_cases = max(8, N_CASES // 4)
     failures = []
     for case in range(n_cases):
-        seed = SEED0 + 0x300000 + case
+        seed = SEED0 + 0x300000 + case + (0x40000 if hostile else 0)
         ops, fr = _scene_recipe(seed)
         rng = np.random.default_rng(seed ^ 0x13579B)
+        wild = hostile and rng.random() < 0.33       # as in _poison: non-finite numbers hide the whole scene, so most cases stay finite
+        bad_coord = np.array([NAN, INF, -INF, 1e30] if wild else [1e30, -1e30, 1e18, 0.0, 3e-39], np.float32)
+        bad_radius = np.array([0.0, -0.3, INF, NAN, 1e-30, 1e30] if wild else [0.0, -0.3, -2.0, 1e-30, 3e-39, 1e30], np.float32)
         s = engine.Scene(); _apply(s, ops)
         renderer.commit(s)
         arrs = s.arrays()
@@ -260,24 +329,34 @@ def test_random_sphere_and_vertex_updates_on_the_device(orc, renderer):
                     sp["center"][f_][first:first + cnt] += rng.uniform(-0.4, 0.4, cnt).astype(np.float32)
                 sp["radius"][first:first + cnt] *= rng.uniform(0.6, 1.3, cnt).astype(np.float32)
                 sp["albedo"]["Y"][first:first + cnt] = rng.uniform(0.1, 0.9, cnt).astype(np.float32)
+                if hostile:
+                    for _ in range(int(rng.integers(1, 4))):
+                        i_ = first + int(rng.integers(0, cnt))
+                        if rng.random() < 0.5: sp["center"]["XYZ"[int(rng.integers(0, 3))]][i_] = rng.choice(bad_coord)
+                        else: sp["radius"][i_] = rng.choice(bad_radius)
                 renderer.update_spheres(first, sp[first:first + cnt], policy)
                 arrs["spheres"] = sp
-                want_blas, want_inst = U._refit_sphere_blas_numpy(arrs)
+                with np.errstate(all="ignore"):
+                    want_blas, want_inst = U._refit_sphere_blas_numpy(arrs)
             else:
                 first = int(rng.integers(0, n_pos)); cnt = int(rng.integers(1, n_pos - first + 1))
                 pos = np.stack([arrs["meshPositions"][f_] for f_ in "XYZ"], axis=1)
                 pos[first:first + cnt] += rng.uniform(-0.15, 0.15, (cnt, 3)).astype(np.float32)
+                if hostile:
+                    for _ in range(int(rng.integers(1, 4))):
+                        pos[first + int(rng.integers(0, cnt)), int(rng.integers(0, 3))] = rng.choice(bad_coord)
                 renderer.update_positions(first, pos[first:first + cnt], policy)
                 for k_, f_ in enumerate("XYZ"):
                     arrs["meshPositions"][f_] = pos[:, k_]
-                want_blas, want_inst = U._refit_blas_numpy(arrs)
+                with np.errstate(all="ignore"):
+                    want_blas, want_inst = U._refit_blas_numpy(arrs)
         except engine.HrtError as e:
             if "cannot be refitted" in str(e) or "INVALID_STATE" in str(e) or "refit" in str(e):
                 continue                                     # the library says when a BLAS layout is not one it maintains
             raise
         got_blas = renderer.download_array("blasNodes")
         nodes, idx, inst = U._download(renderer)
-        if policy == T.REBUILD_FORCE_REFIT and (got_blas.tobytes() != want_blas.tobytes() or inst.tobytes() != want_inst.tobytes()):
+        if policy == T.REBUILD_FORCE_REFIT and (H.canon(got_blas).tobytes() != H.canon(want_blas).tobytes() or H.canon(inst).tobytes() != H.canon(want_inst).tobytes()):
             failures.append((seed, what, policy, "device BLAS / instance bounds differ from the numpy refit")); continue
         # (under the other policies the device may have given a BLAS a new topology: the frame is checked over what it holds now)
         arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = got_blas, inst, nodes, idx

@@ -2,6 +2,8 @@
 kernels written independently from the C# (oracle/orc_indep.py: scalar numpy.float32 in the reference's statement order).  Every
 output array of both launches must agree bit for bit.  This does not pin the oracle to the reference binary (nothing can),
 but a transcription slip in either restatement fails here."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,12 +88,18 @@ def test_second_restatement_reuse_frames(orc, moving):
     assert imported > w * h                     # reuse really ran
 
 
-@pytest.mark.parametrize("case", range(14))
-def test_second_restatement_on_random_scenes(orc, case):
+@pytest.mark.parametrize("hostile", [False, True])
+@pytest.mark.parametrize("case", range(int(os.environ.get("HRT_INDEP_CASES", "0")) or 14))
+def test_second_restatement_on_random_scenes(orc, case, hostile):
     """The scene / frame recipes of the GPU differential fuzz (tests/test_fuzz_gpu.py) at postage-stamp size: both restatements of the
-    reference must agree on every array, first frame and (where the recipe has reuse on) the second."""
+    reference must agree on every array, first frame and (where the recipe has reuse on) the second.  hostile: the recipe with
+    non-finite / zero / negative / huge numbers planted in it (NaN boxes, inverted boxes, NaN rays: what each comparison, min and
+    max does with them is restated twice as well)."""
     from tests import test_fuzz_gpu as F
-    ops, fr = F._scene_recipe(0x0DD50000 + case)
+    seed = int(os.environ.get("HRT_INDEP_SEED", "0"), 0) or 0x0DD50000
+    ops, fr = F._scene_recipe(seed + case)
+    if hostile:
+        ops, fr = F._poison(ops, fr, seed + case)
     so = orc.OrcScene()
     F._apply(so, ops)
     arrs = so.arrays()
