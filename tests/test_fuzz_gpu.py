@@ -184,13 +184,14 @@ def test_random_scenes_match_the_oracle(orc, renderer, hostile):
 
 
 @pytest.mark.timeout(1800)
-def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer):
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer, hostile):
     """256..700 one-sphere instances (the second, device-built TLAS is in use for every production walk), some of them exact
     duplicates or near-duplicates of others (equal and almost equal distances), random extents and cameras."""
     n_cases = max(6, N_CASES // 12)
     failures = []
     for case in range(n_cases):
-        rng = np.random.default_rng(SEED0 + 0x100000 + case)
+        rng = np.random.default_rng(SEED0 + 0x100000 + case + (0x40000 if hostile else 0))
         n = int(rng.integers(256, 700))
         ext = float(rng.choice([2.0, 5.0, 12.0]))
         recs = [((0.0, -500.0, 0.0), 500.0, (0.6, 0.6, 0.6), T.SHADING_LAMBERT, 1.0)] if rng.random() < 0.7 else []
@@ -203,6 +204,13 @@ def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer):
                 c, r = (float(rng.uniform(-ext, ext)), float(rng.uniform(0.05, 0.4 * ext)), float(rng.uniform(-ext, ext))), float(rng.uniform(0.03, 0.12) * ext)
             recs.append((tuple(float(v) for v in c), float(r), tuple(float(v) for v in rng.uniform(0.1, 1.0, 3)),
                          int(rng.choice([T.SHADING_LAMBERT] * 4 + [T.SHADING_MIRROR, T.SHADING_GLASS])), 1.5))
+        if hostile:      # finite but absurd (anything non-finite or inverted takes the second tree out of use): points, specks, giants, far away
+            for _ in range(int(rng.integers(1, 6))):
+                j = int(rng.integers(0, len(recs)))
+                c, r, kd, sh, ior = recs[j]
+                if rng.random() < 0.5: r = float(rng.choice([0.0, 1e-30, 3e-39, 1e-6, 1e4 * ext, 1e18, 1e30]))
+                else: c = tuple(float(rng.choice([1e18, -1e18, 1e30, 0.0, 3e-39, 1e6 * ext])) if i == int(rng.integers(0, 3)) else v for i, v in enumerate(c))
+                recs[j] = (c, r, kd, sh, ior)
         order = rng.permutation(len(recs))
 
         def build(b):
