@@ -374,3 +374,69 @@ class IndepScene:
         out["texels"] = np.array(self.texels, T.np_dtype(T.RGBA32)) if self.texels else np.zeros(0, T.np_dtype(T.RGBA32))
         out["texInfos"] = np.array(self.tex_infos, T.np_dtype(T.TexInfo)) if self.tex_infos else np.zeros(0, T.np_dtype(T.TexInfo))
         return out
+
+
+# ---------------------------------------------------------------- Camera.cs / RTRenderer.cs host code, restated a second time
+# `math(name, x)` supplies the shared transcendentals (tan, atan, sin, cos of include/hrt_math.h: XMath's own bits are unknowable
+# here); everything else is scalar float32 in the reference's statement order, with the HOST's Max in Normalize.
+def _sub(a, b): return (a[0] - b[0], a[1] - b[1], a[2] - b[2])
+def _add(a, b): return (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+def _mul(a, s): return (a[0] * s, a[1] * s, a[2] * s)
+def _cross(a, b): return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+def _dot(a, b): return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+def _abs(x): return -x if x < f32(0) else x                                              # Camera.cs Abs: x < 0 ? -x : x (keeps -0 and NaN)
+PI = f32(3.14159265358979323846)
+
+
+def _ortho_basis(forward, up_hint):                                                      # Camera.cs OrthoBasis
+    f = normalize(forward)
+    up = up_hint
+    if _abs(_dot(f, up)) > f32(0.999):
+        up = v3(0, 1, 0)
+        if _abs(_dot(f, up)) > f32(0.999): up = v3(1, 0, 0)
+    u = normalize(_cross(f, up))
+    v = normalize(_cross(u, f))
+    return u, v, (-f[0], -f[1], -f[2])
+
+
+def camera_lookat(math, origin, look_at, up, vfov_degrees, aspect, focus_dist=1.0):      # Camera.cs: the six-argument constructor
+    with np.errstate(all="ignore"):
+        origin, look_at, up = v3(*origin), v3(*look_at), v3(*up)
+        aspect, focus_dist = f32(aspect), f32(focus_dist)
+        theta = f32(vfov_degrees) * (PI / f32(180))
+        half_h = math("tan", f32(0.5) * theta)
+        half_w = aspect * half_h
+        forward = normalize(_sub(look_at, origin))
+        u, v, w = _ortho_basis(forward, up)
+        cam = {"origin": origin, "horizontal": _mul(u, f32(2) * half_w), "vertical": _mul(v, f32(2) * half_h)}
+        cam["lowerLeft"] = _add(_sub(_sub(origin, _mul(u, half_w)), _mul(v, half_h)), _mul(forward, focus_dist))
+        cam["forward"] = normalize(_sub(_add(_add(cam["lowerLeft"], _mul(cam["horizontal"], f32(0.5))), _mul(cam["vertical"], f32(0.5))), origin))
+        cam["right"] = normalize(_cross(cam["forward"], v))
+        cam["up"] = normalize(v)
+        cam["aspect"], cam["fovYRadians"] = aspect, theta
+        return cam
+
+
+def camera_bake(math, cam, pixel_w, pixel_h):                                            # RTRenderer.cs BakeCameraDerived
+    with np.errstate(all="ignore"):
+        c = dict(cam)
+        center = _add(_add(c["lowerLeft"], _mul(c["horizontal"], f32(0.5))), _mul(c["vertical"], f32(0.5)))
+        forward = normalize(_sub(center, c["origin"]))
+        up = normalize(c["vertical"])
+        right = normalize(_cross(forward, up))
+        focus = length(_sub(center, c["origin"]))
+        half_h = f32(0.5) * length(c["vertical"])
+        tan_half = half_h / focus if focus > f32(1e-6) else half_h
+        fov_y = f32(2) * math("atan", tan_half)
+        if length(c["horizontal"]) > f32(1e-6) and length(c["vertical"]) > f32(1e-6):
+            aspect = length(c["horizontal"]) / length(c["vertical"])
+        else:
+            aspect = f32(pixel_w) / f32(max(1, pixel_h))
+        c["forward"], c["up"], c["right"], c["fovYRadians"], c["aspect"] = forward, up, right, fov_y, aspect
+        return c
+
+
+def sun_dir(math, azimuth, elevation):                                                   # RTRenderer.cs:174-178
+    with np.errstate(all="ignore"):
+        az, el = f32(azimuth), f32(elevation)
+        return normalize((math("cos", az) * math("cos", el), math("sin", el), math("sin", az) * math("cos", el)))

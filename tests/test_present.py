@@ -53,6 +53,36 @@ def test_oracle_srgb_round_trip_on_flat_image(orc):
         assert np.all(np.abs((out.view(np.uint32) & 255).astype(int) - v) <= 1), v
 
 
+PRESENT_CASES = [((24, 14), (17, 9), (0.075, 0.10, 1.25)), ((9, 7), (9, 7), (0.075, 0.10, 1.25)), ((5, 3), (23, 11), (0.5, 0.0, 0.0)),
+                 ((1, 1), (6, 4), (0.075, 0.10, 1.25)), ((16, 10), (3, 2), (1.0, 1.0, 5.0)), ((7, 1), (1, 9), (0.0, 0.3, 1.0)),
+                 # parameters nobody would set: NaN / infinite / negative feedback, sharpening and clamp slack (inf * 0 = NaN in Clamp)
+                 ((11, 8), (19, 13), (float("nan"), 0.10, 1.25)), ((11, 8), (19, 13), (0.075, float("inf"), 1.25)),
+                 ((11, 8), (19, 13), (0.075, 0.10, float("inf"))), ((11, 8), (19, 13), (-2.0, -1.0, float("nan")))]
+
+
+@pytest.mark.parametrize("in_size,out_size,knobs", PRESENT_CASES)
+def test_second_restatement_of_the_presentation_kernels(orc, in_size, out_size, knobs):
+    """oracle/orc_post.hpp against oracle/orc_indep_post.py (written from the C# alone): TAAU over three frames of history with
+    changing object ids, blit / bilinear resample, on random images -- every output word and both history arrays."""
+    from oracle import orc_indep_post as P
+    (iw, ih), (ow, oh), (fb, sh, ck) = in_size, out_size, knobs
+    rng = np.random.default_rng(iw * 1000 + ow)
+    taa = P.Taa(lambda x, y: orc.math_eval("pow", np.array([x], np.float32), np.array([y], np.float32))[0])
+    h1 = (np.zeros(ow * oh, np.int32), np.zeros(ow * oh, np.int32))
+    h2 = (np.zeros(ow * oh, np.int32), np.zeros(ow * oh, np.int32))
+    obj = None
+    for f in range(3):
+        color, new_obj = _rand_frame(rng, iw, ih)
+        obj = new_obj if obj is None else np.where(rng.random(iw * ih) < 0.3, new_obj, obj).astype(np.int32)    # most ids persist: history is used
+        want = orc.present(1, color, obj, iw, ih, ow, oh, history=h1, first_frame=(f == 0), feedback=fb, sharpness=sh, clamp_k=ck)
+        got = taa.resolve(color, obj, iw, ih, ow, oh, h2[0], h2[1], f == 0, fb, sh, ck)
+        assert np.array_equal(want, got), "TAAU frame %d" % f
+        assert np.array_equal(h1[0], h2[0]) and np.array_equal(h1[1], h2[1])
+        want = orc.present(0, color, None, iw, ih, ow, oh)
+        got = P.blit(color, ow * oh) if (iw, ih) == (ow, oh) else P.bilinear_upsample(color, iw, ih, ow, oh)
+        assert np.array_equal(want, got), "resample frame %d" % f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["log", "exp", "pow"])
 def test_pow_family_bit_exact_on_gpu(orc, renderer, name):
@@ -94,6 +124,27 @@ def test_present_matches_oracle(orc, renderer, out_size, scale):
         assert np.array_equal(got_rs, want_rs), "resample frame %d" % f
     v = renderer.device_views(0)
     assert v.present_color and v.present_width == ow and v.present_height == oh
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [(float("nan"), 0.10, 1.25), (0.075, float("inf"), 1.25), (0.075, 0.10, float("inf")), (0.9, 3.0, 1e30), (1e-30, 1e-30, 1e-30)])
+def test_present_with_unusual_knobs(orc, renderer, knobs):
+    """TAAU tunables nobody would set (NaN feedback, infinite sharpening, an infinite clamp slack -- `k * 0.0f` is NaN then): three
+    frames of history, every output word against the oracle."""
+    fb, sh, ck = knobs
+    ow, oh, in_w, in_h = 96, 54, 64, 36
+    s = engine.Scene(); scenes.build_config2(s); renderer.commit(s)
+    renderer.reset_history()
+    cfg = scenes.CONFIGS[2]
+    hist = (np.zeros(ow * oh, np.int32), np.zeros(ow * oh, np.int32))
+    for f in range(3):
+        c2 = scenes.Config("p", in_w, in_h, 1, cfg.cam_origin, cfg.cam_lookat, extra={"sun_azimuth": 1.5707963 + 0.02 * f, "sun_elevation": 0.6})
+        p = scenes.frame_params(c2, *H.host_funcs("hrt"), frame=f)
+        low, o = T.alloc_outputs(in_w, in_h, ["color", "objectId"])
+        renderer.render_params(p, o)
+        got = renderer.present(ow, oh, taau=True, feedback=fb, sharpness=sh, clamp_k=ck)
+        want = orc.present(1, low["color"], low["objectId"], in_w, in_h, ow, oh, history=hist, first_frame=(f == 0), feedback=fb, sharpness=sh, clamp_k=ck)
+        assert np.array_equal(got, want), "TAAU frame %d" % f
 
 
 @pytest.mark.gpu
