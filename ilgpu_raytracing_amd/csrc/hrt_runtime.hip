@@ -2322,9 +2322,9 @@ try {
         k.outColor = d.present_color; k.inColorLow = d.fb.color; k.inObjIdLow = d.fb.objectId;
         k.historyColor = d.taa_hist_color; k.historyObjId = d.taa_hist_obj;
         k.outW = outW; k.outH = outH; k.inW = inW; k.inH = inH;
-        k.feedback = pp->feedback > 0.f ? pp->feedback : 0.075f;           // tunables of RTTaa.cs:77-79
-        k.sharpness = pp->sharpness > 0.f ? pp->sharpness : 0.10f;
-        k.clampK = pp->clampK > 0.f ? pp->clampK : 1.25f;
+        k.feedback = pp->feedback <= 0.f ? 0.075f : pp->feedback;          // tunables of RTTaa.cs:77-79; "<= 0 selects the default" as the
+        k.sharpness = pp->sharpness <= 0.f ? 0.10f : pp->sharpness;        // header says: a NaN is not <= 0 and goes through to the kernel,
+        k.clampK = pp->clampK <= 0.f ? 1.25f : pp->clampK;                 // as a NaN written to the reference's public fields would
         k.isFirstFrame = d.taa_history_valid ? 0 : 1;
         hipLaunchKernelGGL(hrt_taa_resolve_kernel, dim3(std::min(blocks, 256 * 16)), dim3(256), 0, d.stream, k);
         d.taa_history_valid = true;
