@@ -16,6 +16,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <cmath>
+#include <utility>
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
 #include "hrt_wavefront.hpp"
@@ -344,7 +346,7 @@ struct DeviceState {
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     // a second tree over the same instances, built on the device at upload: what boolean queries of fast-sphere scenes walk
     TlasDevice tl2{};
-    void* tl2mem[15] = {};
+    void* tl2mem[16] = {};
     DPacked dpackedAny{};
     bool any_ok = false;
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
@@ -527,7 +529,7 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
-    for (int i = 0; i < 15; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+    for (int i = 0; i < 16; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
     d.tl2 = TlasDevice{}; d.any_ok = false;
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
@@ -1710,6 +1712,69 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 // second tree is built over "the instances").  Dropped again by the first scene update (the tree in use is then device-built
 // anyway, or its boxes have moved).
 constexpr int64_t kAnyTreeMinInstances = 256;
+
+// The inlined second tree (TlasDevice::tlasX: nodes in walk order, every leaf followed by one record per instance) renumbered for the
+// rays whose direction has the signs `sign` (+1 / -1 per axis, 0: not known): at every inner node the child whose box centre comes first along such a ray,
+// on the axis that separates the two centres most, is walked first.  Same records, same subtree sizes; only the order of the two
+// subtrees under a node, and with it every link, changes.  Links are written as indices into the array of all eight copies
+// (`base` = where this copy starts).  false: the array is not the binary tree in walk order it should be (nothing is used then).
+bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int base, NodeQ* out)
+{
+    const int nX = (int)X.size();
+    auto w_ = [](float f) { return __builtin_bit_cast(int, f); };
+    auto f_ = [](int v) { return __builtin_bit_cast(float, v); };
+    auto cnt = [&](int i) { return (int)((unsigned)w_(X[(size_t)i].hi.w) >> 28); };
+    auto end = [&](int i) { const int sk = w_(X[(size_t)i].hi.w) & kEnd; return sk == kEnd ? nX : sk; };
+    std::vector<std::pair<int, int>> todo;                  // (record in X, its index in this numbering)
+    todo.emplace_back(0, 0);
+    int placed = 0;
+    while (!todo.empty())
+    {
+        const int src = todo.back().first, at = todo.back().second;
+        todo.pop_back();
+        if (src < 0 || src >= nX || at < 0 || at >= nX) return false;
+        const int size = end(src) - src;
+        if (size < 1 || at + size > nX) return false;
+        const int skip = at + size == nX ? kEnd : base + at + size;
+        const int c = cnt(src);
+        NodeQ q = X[(size_t)src];
+        if (c == 15) return false;                          // an instance record where a node should be
+        if (c > 0)
+        {
+            if (size != 1 + c) return false;
+            q.hi.w = f_(skip | (int)((unsigned)c << 28));
+            out[at] = q;
+            for (int j = 0; j < c; j++)
+            {
+                NodeQ r = X[(size_t)(src + 1 + j)];
+                if (cnt(src + 1 + j) != 15) return false;
+                r.hi.w = f_((j + 1 < c ? base + at + 2 + j : skip) | (int)(15u << 28));
+                out[at + 1 + j] = r;
+            }
+            placed += 1 + c;
+            continue;
+        }
+        const int l = w_(q.lo.w) & kEnd;
+        if (l != src + 1 || l >= nX) return false;
+        const int r = end(l);
+        if (r >= nX || end(r) != end(src)) return false;    // exactly two children
+        const NodeQ &L = X[(size_t)l], &R = X[(size_t)r];
+        const float cl[3] = {0.5f * (L.lo.x + L.hi.x), 0.5f * (L.lo.y + L.hi.y), 0.5f * (L.lo.z + L.hi.z)};
+        const float cr[3] = {0.5f * (R.lo.x + R.hi.x), 0.5f * (R.lo.y + R.hi.y), 0.5f * (R.lo.z + R.hi.z)};
+        int ax = 0;
+        for (int a = 1; a < 3; a++) if (std::fabs(cl[a] - cr[a]) > std::fabs(cl[ax] - cr[ax])) ax = a;
+        // +1 / -1: the rays of this copy go that way along ax; 0: either way -- the builder's order stays (lower Morton code first)
+        const bool leftFirst = sign[ax] > 0 ? cl[ax] <= cr[ax] : (sign[ax] < 0 ? cl[ax] >= cr[ax] : true);
+        const int a = leftFirst ? l : r, b = leftFirst ? r : l;
+        q.lo.w = f_(base + at + 1);
+        q.hi.w = f_(skip);
+        out[at] = q;
+        placed += 1;
+        todo.emplace_back(b, at + 1 + (end(a) - a));
+        todo.emplace_back(a, at + 1);
+    }
+    return placed == nX;
+}
 int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce)
 {
     d.any_ok = false;
@@ -1761,6 +1826,56 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     d.dpackedAny.tlas = T.tlas; d.dpackedAny.finst = T.finst; d.dpackedAny.nTlas = T.nT;
     d.dpackedAny.tlasX = T.tlasX; d.dpackedAny.nTlasX = T.nT + T.nTI;
     d.dpackedAny.slotMap = (const int*)d.tl2mem[14];
+    d.dpackedAny.tlasXO = nullptr; d.dpackedAny.xStride = 0; d.dpackedAny.xAxes = 0;
+    if (d.tl2mem[15]) { (void)hipFree(d.tl2mem[15]); d.tl2mem[15] = nullptr; }
+#ifndef HRT_NO_ORDERED_COPIES      // A/B
+    // Which signs select a numbering: the two axes along which the instances are spread most (extent of the box centres between their
+    // 5th and 95th percentile: one huge ground sphere must not count), as long as the copies stay within a budget that leaves them in the
+    // L2 -- measured on config 3 (22 k records, 0.7 MB a copy): x and z 16.2 ms, z 16.8, x 16.7, all three 18.1, none 17.5, y alone 18.9
+    // (along y the builder's order, ground first, is the better one: one sphere test bounds every ray that goes down).
+    const int nX = T.nT + T.nTI;
+    constexpr size_t kOrderedBudget = 4u << 20;
+    int axes = 0;
+    {
+        std::vector<hrt_instance> inst((size_t)c->n_inst);
+        HIPCHK(c, hipMemcpy(inst.data(), T.instances, inst.size() * sizeof(hrt_instance), hipMemcpyDeviceToHost));
+        float ext[3];
+        std::vector<float> v(inst.size());
+        for (int a = 0; a < 3; a++)
+        {
+            for (size_t i = 0; i < inst.size(); i++)
+                v[i] = a == 0 ? inst[i].worldBoundsMin.X + inst[i].worldBoundsMax.X : (a == 1 ? inst[i].worldBoundsMin.Y + inst[i].worldBoundsMax.Y : inst[i].worldBoundsMin.Z + inst[i].worldBoundsMax.Z);
+            for (float& x : v) if (!std::isfinite(x)) x = 0.f;       // (an ordering for std::sort; infinite boxes are legal here)
+            std::sort(v.begin(), v.end());
+            ext[a] = v[v.size() - 1 - v.size() / 20] - v[v.size() / 20];
+        }
+        int order[3] = {0, 1, 2};
+        std::sort(order, order + 3, [&](int p, int q) { return ext[p] > ext[q] || (ext[p] == ext[q] && p < q); });
+        for (int k = 0; k < 2; k++)
+            if (ext[order[k]] > 0.f && ext[order[k]] >= 0.25f * ext[order[0]] && (size_t)nX * sizeof(NodeQ) * (size_t)ord_copies(axes | (1 << order[k])) <= kOrderedBudget)
+                axes |= 1 << order[k];
+    }
+    const int copies = ord_copies(axes);
+    if (axes != 0 && (int64_t)nX * copies < kEnd)
+    {
+        std::vector<NodeQ> X((size_t)nX), all((size_t)nX * (size_t)copies);
+        HIPCHK(c, hipMemcpy(X.data(), T.tlasX, (size_t)nX * sizeof(NodeQ), hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (int o = 0; ok && o < copies; o++)
+        {
+            int sign[3] = {0, 0, 0};
+            for (int a = 0; a < 3; a++)      // the copy bit of axis a = the index of a direction that is positive along a only
+                if (axes & (1 << a)) sign[a] = (ord_copy(axes, a == 0 ? 1.f : -1.f, a == 1 ? 1.f : -1.f, a == 2 ? 1.f : -1.f) & o) ? 1 : -1;
+            ok = reorder_second_tree(X, sign, o * nX, all.data() + (size_t)o * (size_t)nX);
+        }
+        if (ok)
+        {
+            HIPCHK(c, hipMalloc(&d.tl2mem[15], all.size() * sizeof(NodeQ)));
+            HIPCHK(c, hipMemcpy(d.tl2mem[15], all.data(), all.size() * sizeof(NodeQ), hipMemcpyHostToDevice));
+            d.dpackedAny.tlasXO = (const NodeQ*)d.tl2mem[15]; d.dpackedAny.xStride = nX; d.dpackedAny.xAxes = axes;
+        }
+    }
+#endif
     d.any_ok = true;
     return HRT_OK;
 }

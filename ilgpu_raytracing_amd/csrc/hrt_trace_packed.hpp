@@ -44,6 +44,18 @@ constexpr int kWNone = (int)0x80000000;
 enum { FI_FAST_SPHERE = 1, FI_IDENTITY = 2, FI_SPHERESET = 4 };
 enum { FT_TEXTURED = 1, FT_TWOSIDED = 2 };  // FT_TEXTURED: usable diffuse or alpha map, or AlphaCutoff > 1 (rejects alpha = 1)
 
+// Numberings of the second tree (DPacked::tlasXO): `axes` (bit a: axis a) says which signs of a ray's direction select one; the copy
+// index packs those signs, lowest selected axis first.
+HRT_HD int ord_copy(int axes, float dx, float dy, float dz)
+{
+    int k = 0, b = 0;
+    if (axes & 1) { k |= (dx > 0.f ? 1 : 0) << b; b++; }
+    if (axes & 2) { k |= (dy > 0.f ? 1 : 0) << b; b++; }
+    if (axes & 4) { k |= (dz > 0.f ? 1 : 0) << b; b++; }
+    return k;
+}
+HRT_HD int ord_copies(int axes) { return 1 << ((axes & 1) + ((axes >> 1) & 1) + ((axes >> 2) & 1)); }
+
 struct DPacked {
     const NodeQ* tlas;
     const FInst* finst;      // indexed like tlasInstanceIndices
@@ -56,6 +68,10 @@ struct DPacked {
     int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
     int leafTris;            // triangle records the walker fetches per leaf step (2 or 3: hrt_walker.hpp)
     const int* slotMap;      // second tree over the same instances (hrt_walker.hpp, ALT): leaf slot of the uploaded tree -> leaf slot here; else nullptr
+    const NodeQ* tlasXO;     // second tree only: tlasX two or four times over, one numbering per combination of the signs of a ray's direction along
+    int xStride;             //   the axes xAxes (ord_copy), with the child that is nearer along such a ray first; copy o occupies
+    int xAxes;               //   [o * xStride, (o + 1) * xStride) and its links are indices into the whole array.  Leaf slots (finst, slotMap) are
+                             //   shared by all copies.  nullptr: not built
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514

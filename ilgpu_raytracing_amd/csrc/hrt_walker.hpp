@@ -77,6 +77,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
     // sphere-instance scenes: instance records are inlined into the node stream (DPacked::tlasX); a leaf hit just walks on
     // into them, an instance-record hit leaves ONE sphere test pending for the leaf step
     const bool inl = !kGeneral && tr.P.tlasX != nullptr;
+    // the second tree in several child orders (DPacked::tlasXO): a ray walks the numbering of its direction's signs, in which the nearer
+    // child of an inner node comes first -- a fixed-order walk then prunes the farther one against what it found in the nearer
+    // (profiles/r02_walk_experiments.txt (14), (15): config 3's path stage -7.5 % with four numberings).  Which numbering a ray
+    // walks changes no result: the walks over the second tree do not depend on the order (see above and hrt_trace_packed.hpp).
+    const bool ord = ALT && inl && tr.P.tlasXO != nullptr;
     __shared__ float park_mem[kGeneral ? 9 : 1][256];
     RayPark park; park.sh = park_mem;
     const DPacked& P = tr.P;
@@ -98,6 +103,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
     float bestT = 1e30f, bestTObj = 0.f; int bestSlot = -1, bestPrim = -1;     // closest
     bool occl = false, tie = false, anom = false;
     int cur = 0, li = 0, lend = 0, lskip = kEnd;          // TLAS walk / leaf iteration
+    int xlast = tr.P.nTlasX - 1;                           // last record of the node array this lane walks (ord: of its octant's copy)
     int bj = 0, bend = 0, bskip = kEnd;                   // BLAS leaf iteration
     int blasEnd = 0, iflags = 0, islot = 0; float iscale = 1.f, tObj = 1e30f; int iprim = -1;   // instance being walked
 
@@ -129,6 +135,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                         if (fetch(rayIdx, w, tMaxW))
                         {
                             C.inc(ANY ? C_RAYS_SHADOW : C_RAYS_CLOSEST); cur = 0; mode = M_TLAS;
+                            if (ord)
+                            {
+                                cur = ord_copy(P.xAxes, w.d.x, w.d.y, w.d.z) * P.xStride;
+                                xlast = cur + P.xStride - 1;
+                            }
                             // the tree-independence argument needs finite slab arithmetic: this ray walks the uploaded tree (at retirement)
                             if (ALT && !finite_ray(w)) { tie = true; mode = M_DONE; }
                         }
@@ -153,11 +164,11 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
             if (walking)
             {
                 const bool top = !kGeneral || mode == M_TLAS;
-                const NodeQ* nodes = top ? (inl ? P.tlasX : P.tlas) : P.blas;
+                const NodeQ* nodes = top ? (inl ? (ord ? P.tlasXO : P.tlasX) : P.tlas) : P.blas;
                 // In walk order the node entered after a hit on an inner node is the next record, usually in the same
                 // 128-byte line: it is fetched together with the node itself, so a hit costs no second memory round trip
                 // (the walk is bound by the latency of dependent loads, not by their number).
-                const int last = (top ? (inl ? P.nTlasX : P.nTlas) : blasEnd) - 1;
+                const int last = top ? (inl ? xlast : P.nTlas - 1) : blasEnd - 1;
                 // kLook consecutive records leave together (one or two 128-byte lines)
                 NodeQ nds[kLook];
 #pragma unroll
