@@ -81,7 +81,13 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
     // child of an inner node comes first -- a fixed-order walk then prunes the farther one against what it found in the nearer
     // (profiles/r02_walk_experiments.txt (14), (15): config 3's path stage -7.5 % with four numberings).  Which numbering a ray
     // walks changes no result: the walks over the second tree do not depend on the order (see above and hrt_trace_packed.hpp).
+    // Only closest-hit walks that run to the end: a walk that stops at its first hit (any-hit, EXISTS) gains nothing from meeting the
+    // nearer child first and would only share the L2 with three more copies.
+#ifdef HRT_ORD_ALL                 // A/B
     const bool ord = ALT && inl && tr.P.tlasXO != nullptr;
+#else
+    const bool ord = kTies && inl && tr.P.tlasXO != nullptr;
+#endif
     __shared__ float park_mem[kGeneral ? 9 : 1][256];
     RayPark park; park.sh = park_mem;
     const DPacked& P = tr.P;
