@@ -17,6 +17,7 @@
 #include <thread>
 #include <vector>
 #include <cmath>
+#include <cfloat>
 #include <utility>
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
@@ -1713,6 +1714,109 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 // anyway, or its boxes have moved).
 constexpr int64_t kAnyTreeMinInstances = 256;
 
+// Topology of the second tree built on the HOST with a binned surface-area heuristic (16 bins on each axis over the box centres of
+// the range, the split of least area(left) * n(left) + area(right) * n(right); leaves of at most four instances; a range the bins cannot
+// split is halved), in the numbering the walkers want (walk order: a node's first child follows it).
+// Only WHICH instances share a subtree is decided here -- boxes, leaf-slot records, the inlined layout and the slack are the
+// device's (tlas_finish, tlas_inflate), exactly as for the LBVH the scene updates build.  Against that LBVH: 6-10 % fewer node
+// visits per ray on config 3 (tools/tree_order_model.py); the scene updates keep the LBVH, which is built in 0.3 ms.
+constexpr int64_t kHostSahMaxInstances = 1 << 18;
+constexpr int kSahLeaf = 4;       // instances per leaf at most (config 3, path stage + launch 1: 15.66 / 15.37 / 15.39 / 15.41 ms for 2 / 3 / 4 / 6)
+struct SahTopology { std::vector<int32_t> order; std::vector<NodeQ> nodes; std::vector<int> parent, nchild; int leaves = 0; };
+void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)
+{
+    const int n = (int)inst.size();
+    constexpr int kBins = 16;
+    std::vector<float> cx((size_t)n), cy((size_t)n), cz((size_t)n);
+    for (int i = 0; i < n; i++)
+    {
+        cx[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.X + inst[(size_t)i].worldBoundsMax.X);
+        cy[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.Y + inst[(size_t)i].worldBoundsMax.Y);
+        cz[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.Z + inst[(size_t)i].worldBoundsMax.Z);
+    }
+    const float* cen[3] = {cx.data(), cy.data(), cz.data()};
+    struct Box { float lo[3], hi[3]; };
+    auto grow = [&](Box& b, int i) {
+        const hrt_instance& r = inst[(size_t)i];
+        const float l[3] = {r.worldBoundsMin.X, r.worldBoundsMin.Y, r.worldBoundsMin.Z}, h[3] = {r.worldBoundsMax.X, r.worldBoundsMax.Y, r.worldBoundsMax.Z};
+        for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], l[a]); b.hi[a] = std::max(b.hi[a], h[a]); }
+    };
+    auto unite = [](Box& b, const Box& o) { for (int a = 0; a < 3; a++) { b.lo[a] = std::min(b.lo[a], o.lo[a]); b.hi[a] = std::max(b.hi[a], o.hi[a]); } };
+    auto area = [](const Box& b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x * y + y * z + z * x; };
+    const Box empty = {{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    out.order.resize((size_t)n);
+    for (int i = 0; i < n; i++) out.order[(size_t)i] = i;
+    out.nodes.clear(); out.parent.clear(); out.nchild.clear(); out.leaves = 0;
+    struct Job { int a, b, parent; };
+    std::vector<Job> todo;
+    todo.push_back({0, n, -1});
+    while (!todo.empty())
+    {
+        const Job j = todo.back();
+        todo.pop_back();
+        const int idx = (int)out.nodes.size();
+        NodeQ q{};
+        out.parent.push_back(j.parent);
+        const int m = j.b - j.a;
+        if (m <= kSahLeaf)
+        {
+            q.lo.w = bits_f(j.a);
+            q.hi.w = bits_f((int)((unsigned)m << 28));           // the skip link comes with the subtree sizes, below
+            out.nodes.push_back(q); out.nchild.push_back(0); out.leaves++;
+            continue;
+        }
+        int32_t* it = out.order.data() + j.a;
+        int bestAxis = -1, bestK = 0; float bestCost = 0.f, bestLo = 0.f, bestScale = 0.f;
+        for (int a = 0; a < 3; a++)
+        {
+            float lo = FLT_MAX, hi = -FLT_MAX;
+            for (int i = 0; i < m; i++) { lo = std::min(lo, cen[a][it[i]]); hi = std::max(hi, cen[a][it[i]]); }
+            if (!(hi > lo) || !std::isfinite(hi - lo)) continue;
+            const float scale = (float)kBins / (hi - lo);
+            Box bb[kBins]; int cnt[kBins];
+            for (int k = 0; k < kBins; k++) { bb[k] = empty; cnt[k] = 0; }
+            for (int i = 0; i < m; i++)
+            {
+                const int k = std::min(kBins - 1, std::max(0, (int)((cen[a][it[i]] - lo) * scale)));
+                grow(bb[k], it[i]); cnt[k]++;
+            }
+            Box right[kBins]; int rcnt[kBins];
+            Box acc = empty; int c = 0;
+            for (int k = kBins - 1; k >= 1; k--) { unite(acc, bb[k]); c += cnt[k]; right[k] = acc; rcnt[k] = c; }
+            acc = empty; c = 0;
+            for (int k = 1; k < kBins; k++)
+            {
+                unite(acc, bb[k - 1]); c += cnt[k - 1];
+                if (c == 0 || rcnt[k] == 0) continue;
+                const float cost = area(acc) * (float)c + area(right[k]) * (float)rcnt[k];
+                if (std::isfinite(cost) && (bestAxis < 0 || cost < bestCost)) { bestAxis = a; bestK = k; bestCost = cost; bestLo = lo; bestScale = scale; }
+            }
+        }
+        int mid = m / 2;
+        if (bestAxis >= 0)
+        {
+            const float* ca = cen[bestAxis];
+            int32_t* p2 = std::partition(it, it + m, [&](int32_t i) { return std::min(kBins - 1, std::max(0, (int)((ca[i] - bestLo) * bestScale))) < bestK; });
+            const int left = (int)(p2 - it);
+            if (left > 0 && left < m) mid = left;
+        }
+        q.lo.w = bits_f(idx + 1);
+        out.nodes.push_back(q); out.nchild.push_back(2);
+        todo.push_back({j.a + mid, j.b, idx});       // popped second: the first child is the next node
+        todo.push_back({j.a, j.a + mid, idx});
+    }
+    // skip link = index + size of the subtree (walk order: children have larger indices than their parent)
+    const int nT = (int)out.nodes.size();
+    std::vector<int> size((size_t)nT, 1);
+    for (int i = nT - 1; i > 0; i--) size[(size_t)out.parent[(size_t)i]] += size[(size_t)i];
+    for (int i = 0; i < nT; i++)
+    {
+        const int end = i + size[(size_t)i];
+        const int w = __builtin_bit_cast(int, out.nodes[(size_t)i].hi.w);
+        out.nodes[(size_t)i].hi.w = bits_f((w & ~kEnd) | (end >= nT ? kEnd : end));
+    }
+}
+
 // The inlined second tree (TlasDevice::tlasX: nodes in walk order, every leaf followed by one record per instance) renumbered for the
 // rays whose direction has the signs `sign` (+1 / -1 per axis, 0: not known): at every inner node the child whose box centre comes first along such a ray,
 // on the axis that separates the two centres most, is walked first.  Same records, same subtree sizes; only the order of the two
@@ -1799,6 +1903,23 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     T.scanIn = (unsigned long long*)d.tl2mem[9]; T.scanOut = (unsigned long long*)d.tl2mem[10]; T.sa = (float*)d.tl2mem[11]; T.saBase = (float*)d.tl2mem[12];
     T.flags = (int*)d.tl2mem[13]; T.cost = (float*)((char*)d.tl2mem[13] + 16);
     int leaves = 0;
+    std::vector<hrt_instance> inst((size_t)c->n_inst);
+    HIPCHK(c, hipMemcpy(inst.data(), T.instances, inst.size() * sizeof(hrt_instance), hipMemcpyDeviceToHost));
+#ifndef HRT_NO_HOST_SAH            // A/B
+    if (c->n_inst <= kHostSahMaxInstances && c->n_inst > 2)
+    {
+        SahTopology sah;
+        host_sah_topology(inst, sah);
+        T.nT = (int)sah.nodes.size(); T.nTI = (int)c->n_inst; leaves = sah.leaves;
+        if (T.nT > T.capT || T.nTI > T.capTI || T.nT != 2 * leaves - 1) return fail(c, HRT_ERR_HIP, "second tree: host topology does not fit");
+        HIPCHK(c, hipMemcpyAsync(T.tlas, sah.nodes.data(), sah.nodes.size() * sizeof(NodeQ), hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, hipMemcpyAsync(T.tlasInst, sah.order.data(), sah.order.size() * 4, hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, hipMemcpyAsync(T.parent, sah.parent.data(), sah.parent.size() * 4, hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, hipMemcpyAsync(T.nchild, sah.nchild.data(), sah.nchild.size() * 4, hipMemcpyHostToDevice, d.stream));
+        HIPCHK(c, hipStreamSynchronize(d.stream));              // the vectors go out of scope
+    }
+    else
+#endif
     HIPCHK(c, tlas_rebuild_topology(T, d.stream, &leaves));
     T.directMax = 63;                                           // emitted in walk order
     HIPCHK(c, tlas_finish(T, d.stream));
@@ -1837,8 +1958,6 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     constexpr size_t kOrderedBudget = 4u << 20;
     int axes = 0;
     {
-        std::vector<hrt_instance> inst((size_t)c->n_inst);
-        HIPCHK(c, hipMemcpy(inst.data(), T.instances, inst.size() * sizeof(hrt_instance), hipMemcpyDeviceToHost));
         float ext[3];
         std::vector<float> v(inst.size());
         for (int a = 0; a < 3; a++)
