@@ -1733,6 +1733,10 @@ void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)
         cx[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.X + inst[(size_t)i].worldBoundsMax.X);
         cy[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.Y + inst[(size_t)i].worldBoundsMax.Y);
         cz[(size_t)i] = 0.5f * (inst[(size_t)i].worldBoundsMin.Z + inst[(size_t)i].worldBoundsMax.Z);
+        // (an infinite box is legal here; its centre only has to be a number the binning can convert to an integer)
+        if (!std::isfinite(cx[(size_t)i])) cx[(size_t)i] = 0.f;
+        if (!std::isfinite(cy[(size_t)i])) cy[(size_t)i] = 0.f;
+        if (!std::isfinite(cz[(size_t)i])) cz[(size_t)i] = 0.f;
     }
     const float* cen[3] = {cx.data(), cy.data(), cz.data()};
     struct Box { float lo[3], hi[3]; };
@@ -1822,7 +1826,7 @@ void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)
 // on the axis that separates the two centres most, is walked first.  Same records, same subtree sizes; only the order of the two
 // subtrees under a node, and with it every link, changes.  Links are written as indices into the array of all eight copies
 // (`base` = where this copy starts).  false: the array is not the binary tree in walk order it should be (nothing is used then).
-bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int base, NodeQ* out)
+bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int base, NodeQ* out, bool inlined)
 {
     const int nX = (int)X.size();
     auto w_ = [](float f) { return __builtin_bit_cast(int, f); };
@@ -1845,9 +1849,11 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
         if (c == 15) return false;                          // an instance record where a node should be
         if (c > 0)
         {
-            if (size != 1 + c) return false;
+            if (size != (inlined ? 1 + c : 1)) return false;
             q.hi.w = f_(skip | (int)((unsigned)c << 28));
             out[at] = q;
+            placed += size;
+            if (!inlined) continue;                         // the plain node array: a leaf names its slots, no records follow
             for (int j = 0; j < c; j++)
             {
                 NodeQ r = X[(size_t)(src + 1 + j)];
@@ -1855,7 +1861,6 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
                 r.hi.w = f_((j + 1 < c ? base + at + 2 + j : skip) | (int)(15u << 28));
                 out[at + 1 + j] = r;
             }
-            placed += 1 + c;
             continue;
         }
         const int l = w_(q.lo.w) & kEnd;
@@ -1947,7 +1952,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     d.dpackedAny.tlas = T.tlas; d.dpackedAny.finst = T.finst; d.dpackedAny.nTlas = T.nT;
     d.dpackedAny.tlasX = T.tlasX; d.dpackedAny.nTlasX = T.nT + T.nTI;
     d.dpackedAny.slotMap = (const int*)d.tl2mem[14];
-    d.dpackedAny.tlasXO = nullptr; d.dpackedAny.xStride = 0; d.dpackedAny.xAxes = 0;
+    d.dpackedAny.tlasXO = nullptr; d.dpackedAny.xStride = 0; d.dpackedAny.xAxes = 0; d.dpackedAny.tlasO = nullptr; d.dpackedAny.oStride = 0;
     if (d.tl2mem[15]) { (void)hipFree(d.tl2mem[15]); d.tl2mem[15] = nullptr; }
 #ifndef HRT_NO_ORDERED_COPIES      // A/B
     // Which signs select a numbering: the two axes along which the instances are spread most (extent of the box centres between their
@@ -1985,13 +1990,26 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
             int sign[3] = {0, 0, 0};
             for (int a = 0; a < 3; a++)      // the copy bit of axis a = the index of a direction that is positive along a only
                 if (axes & (1 << a)) sign[a] = (ord_copy(axes, a == 0 ? 1.f : -1.f, a == 1 ? 1.f : -1.f, a == 2 ? 1.f : -1.f) & o) ? 1 : -1;
-            ok = reorder_second_tree(X, sign, o * nX, all.data() + (size_t)o * (size_t)nX);
+            ok = reorder_second_tree(X, sign, o * nX, all.data() + (size_t)o * (size_t)nX, true);
+        }
+        // ... and of the plain node array, for launch 1 (both in one allocation: the inlined copies first)
+        const int nP = T.nT;
+        std::vector<NodeQ> Pn((size_t)nP), allP((size_t)nP * (size_t)copies);
+        HIPCHK(c, hipMemcpy(Pn.data(), T.tlas, (size_t)nP * sizeof(NodeQ), hipMemcpyDeviceToHost));
+        for (int o = 0; ok && o < copies; o++)
+        {
+            int sign[3] = {0, 0, 0};
+            for (int a = 0; a < 3; a++)
+                if (axes & (1 << a)) sign[a] = (ord_copy(axes, a == 0 ? 1.f : -1.f, a == 1 ? 1.f : -1.f, a == 2 ? 1.f : -1.f) & o) ? 1 : -1;
+            ok = reorder_second_tree(Pn, sign, o * nP, allP.data() + (size_t)o * (size_t)nP, false);
         }
         if (ok)
         {
-            HIPCHK(c, hipMalloc(&d.tl2mem[15], all.size() * sizeof(NodeQ)));
+            HIPCHK(c, hipMalloc(&d.tl2mem[15], (all.size() + allP.size()) * sizeof(NodeQ)));
             HIPCHK(c, hipMemcpy(d.tl2mem[15], all.data(), all.size() * sizeof(NodeQ), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy((NodeQ*)d.tl2mem[15] + all.size(), allP.data(), allP.size() * sizeof(NodeQ), hipMemcpyHostToDevice));
             d.dpackedAny.tlasXO = (const NodeQ*)d.tl2mem[15]; d.dpackedAny.xStride = nX; d.dpackedAny.xAxes = axes;
+            d.dpackedAny.tlasO = (const NodeQ*)d.tl2mem[15] + all.size(); d.dpackedAny.oStride = nP;
         }
     }
 #endif

@@ -72,6 +72,8 @@ struct DPacked {
     int xStride;             //   the axes xAxes (ord_copy), with the child that is nearer along such a ray first; copy o occupies
     int xAxes;               //   [o * xStride, (o + 1) * xStride) and its links are indices into the whole array.  Leaf slots (finst, slotMap) are
                              //   shared by all copies.  nullptr: not built
+    const NodeQ* tlasO;      // the same numberings of the plain node array `tlas` (launch 1 walks that one: closest_raw), copy o at [o * oStride, ...)
+    int oStride;
 };
 
 HRT_D bool hit_box(const Ray& r, float4 lo, float4 hi, float tMin, float tMax)   // SceneDeviceViews.cs:496-514
@@ -126,6 +128,8 @@ HRT_D float box_entry(const Ray& r, float4 lo, float4 hi)
 // tests/test_second_tree_bound.py samples adversarial (ray, sphere) pairs -- pole and silhouette hits, axis-parallel and skimming
 // rays, coordinates from 1e-2 to 1e3, radii from 1e-3 of that up -- against "the grown box's computed entry <= t_i (1 + 2^-7)"
 // (27 million candidates in a one-off run, no exception).
+// The ORDER in which such a walk meets the children of a node is free as well (nothing above uses it): the tree exists in several
+// numberings (DPacked::tlasXO, one per combination of direction signs, near child first) and a closest-hit walk takes its ray's.
 constexpr float kSecondLimit = 1.f + 0x1p-7f;
 
 // The world ray is dead weight while a general instance's BLAS is walked with the object-space
@@ -324,12 +328,20 @@ struct TracerPackedT {
         bestPrim = -1;              // sphere index, or BLAS leaf slot of the triangle
         bool anom = false;          // TIES: the current winner's own slab entry exceeds its hit distance
         int cur = 0;
+        const NodeQ* nodes = P.tlas;
+#ifndef HRT_NO_ORDERED_PRIMARY     // A/B
+        if (TIES && P.tlasO != nullptr)     // the second tree in the numbering of this ray's direction (DPacked::tlasXO): near child first
+        {
+            nodes = P.tlasO;
+            cur = ord_copy(P.xAxes, wray.d.x, wray.d.y, wray.d.z) * P.oStride;
+        }
+#endif
         for (;;)
         {
             int lfirst = 0, lcount = 0, lskip = kEnd;
             while (cur != kEnd)
             {
-                NodeQ n = P.tlas[cur];
+                NodeQ n = nodes[cur];
                 C.inc(C_NODE_VISITS);
                 int sk = wbits(n.hi);
                 int cnt = (int)((unsigned)sk >> 28);
