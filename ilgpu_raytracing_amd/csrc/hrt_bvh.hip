@@ -925,6 +925,37 @@ hipError_t tlas_inflate(const TlasDevice& T, hipStream_t s)
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(kBlock) k_refresh_copies(NodeQ* dst, const NodeQ* src, const int* map, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const NodeQ q = src[map[i]];
+    dst[i].lo.x = q.lo.x; dst[i].lo.y = q.lo.y; dst[i].lo.z = q.lo.z;
+    dst[i].hi.x = q.hi.x; dst[i].hi.y = q.hi.y; dst[i].hi.z = q.hi.z;
+}
+hipError_t tlas_refresh_copies(NodeQ* dst, const NodeQ* src, const int* map, int n, hipStream_t s)
+{
+    if (n > 0) k_refresh_copies<<<blocks_for(n), kBlock, 0, s>>>(dst, src, map, n);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock) k_slot_of_inst(const int32_t* inst, int* slotOfInst, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) slotOfInst[inst[i]] = i;
+}
+__global__ void __launch_bounds__(kBlock) k_slot_map(const int32_t* instInUse, const int* slotOfInst, int* map, int n)
+{
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) map[i] = slotOfInst[instInUse[i]];
+}
+hipError_t tlas_slot_map(const int32_t* instInUse, const int32_t* instSecond, int* slotOfInst, int* map, int n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    k_slot_of_inst<<<blocks_for(n), kBlock, 0, s>>>(instSecond, slotOfInst, n);
+    k_slot_map<<<blocks_for(n), kBlock, 0, s>>>(instInUse, slotOfInst, map, n);
+    return hipGetLastError();
+}
+
 hipError_t tlas_finish(const TlasDevice& T, hipStream_t s)
 {
     hipError_t e;

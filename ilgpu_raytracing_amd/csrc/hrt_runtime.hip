@@ -347,7 +347,9 @@ struct DeviceState {
     void* tlscratch = nullptr;                 // LBVH scratch, allocated on the first rebuild
     // a second tree over the same instances, built on the device at upload: what boolean queries of fast-sphere scenes walk
     TlasDevice tl2{};
-    void* tl2mem[16] = {};
+    void* tl2mem[18] = {};          // [14] slot map, [15] renumbered copies, [16] what they permute, [17] scratch of the slot map
+    bool any_built = false;                    // a second tree exists for this scene (any_ok: and it describes the scene as it is now)
+    size_t ordX = 0, ordP = 0;                 // records in the renumbered copies of tlasX / of tlas
     DPacked dpackedAny{};
     bool any_ok = false;
     bool tlas_base_valid = false;              // saBase holds the node areas of the TLAS as it was last built
@@ -530,8 +532,8 @@ void free_scene(DeviceState& d)
     for (int i = 0; i < 15; i++) { if (d.scene[i]) (void)hipFree(d.scene[i]); d.scene[i] = nullptr; }
     for (int i = 0; i < 7; i++) { if (d.packed[i]) (void)hipFree(d.packed[i]); d.packed[i] = nullptr; }
     for (int i = 0; i < 10; i++) { if (d.tlaux[i]) (void)hipFree(d.tlaux[i]); d.tlaux[i] = nullptr; }
-    for (int i = 0; i < 16; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
-    d.tl2 = TlasDevice{}; d.any_ok = false;
+    for (int i = 0; i < 18; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+    d.tl2 = TlasDevice{}; d.any_ok = false; d.any_built = false; d.ordX = d.ordP = 0;
     if (d.tlscratch) (void)hipFree(d.tlscratch);
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
     for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
@@ -1825,8 +1827,9 @@ void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)
 // rays whose direction has the signs `sign` (+1 / -1 per axis, 0: not known): at every inner node the child whose box centre comes first along such a ray,
 // on the axis that separates the two centres most, is walked first.  Same records, same subtree sizes; only the order of the two
 // subtrees under a node, and with it every link, changes.  Links are written as indices into the array of all eight copies
-// (`base` = where this copy starts).  false: the array is not the binary tree in walk order it should be (nothing is used then).
-bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int base, NodeQ* out, bool inlined)
+// (`base` = where this copy starts); from[i] = the record of X that position i of the copy holds (a refit refreshes the boxes through it).
+// false: the array is not the binary tree in walk order it should be (nothing is used then).
+bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int base, NodeQ* out, int* from, bool inlined)
 {
     const int nX = (int)X.size();
     auto w_ = [](float f) { return __builtin_bit_cast(int, f); };
@@ -1851,7 +1854,7 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
         {
             if (size != (inlined ? 1 + c : 1)) return false;
             q.hi.w = f_(skip | (int)((unsigned)c << 28));
-            out[at] = q;
+            out[at] = q; from[at] = src;
             placed += size;
             if (!inlined) continue;                         // the plain node array: a leaf names its slots, no records follow
             for (int j = 0; j < c; j++)
@@ -1859,7 +1862,7 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
                 NodeQ r = X[(size_t)(src + 1 + j)];
                 if (cnt(src + 1 + j) != 15) return false;
                 r.hi.w = f_((j + 1 < c ? base + at + 2 + j : skip) | (int)(15u << 28));
-                out[at + 1 + j] = r;
+                out[at + 1 + j] = r; from[at + 1 + j] = src + 1 + j;
             }
             continue;
         }
@@ -1877,7 +1880,7 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
         const int a = leftFirst ? l : r, b = leftFirst ? r : l;
         q.lo.w = f_(base + at + 1);
         q.hi.w = f_(skip);
-        out[at] = q;
+        out[at] = q; from[at] = src;
         placed += 1;
         todo.emplace_back(b, at + 1 + (end(a) - a));
         todo.emplace_back(a, at + 1);
@@ -1953,6 +1956,9 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     d.dpackedAny.tlasX = T.tlasX; d.dpackedAny.nTlasX = T.nT + T.nTI;
     d.dpackedAny.slotMap = (const int*)d.tl2mem[14];
     d.dpackedAny.tlasXO = nullptr; d.dpackedAny.xStride = 0; d.dpackedAny.xAxes = 0; d.dpackedAny.tlasO = nullptr; d.dpackedAny.oStride = 0;
+    d.ordX = d.ordP = 0;
+    if (d.tl2mem[17]) { (void)hipFree(d.tl2mem[17]); d.tl2mem[17] = nullptr; }
+    HIPCHK(c, hipMalloc(&d.tl2mem[17], (size_t)nSlots * 4));
     if (d.tl2mem[15]) { (void)hipFree(d.tl2mem[15]); d.tl2mem[15] = nullptr; }
 #ifndef HRT_NO_ORDERED_COPIES      // A/B
     // Which signs select a numbering: the two axes along which the instances are spread most (extent of the box centres between their
@@ -1983,6 +1989,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     if (axes != 0 && (int64_t)nX * copies < kEnd)
     {
         std::vector<NodeQ> X((size_t)nX), all((size_t)nX * (size_t)copies);
+        std::vector<int> from((size_t)(nX + T.nT) * (size_t)copies);
         HIPCHK(c, hipMemcpy(X.data(), T.tlasX, (size_t)nX * sizeof(NodeQ), hipMemcpyDeviceToHost));
         bool ok = true;
         for (int o = 0; ok && o < copies; o++)
@@ -1990,7 +1997,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
             int sign[3] = {0, 0, 0};
             for (int a = 0; a < 3; a++)      // the copy bit of axis a = the index of a direction that is positive along a only
                 if (axes & (1 << a)) sign[a] = (ord_copy(axes, a == 0 ? 1.f : -1.f, a == 1 ? 1.f : -1.f, a == 2 ? 1.f : -1.f) & o) ? 1 : -1;
-            ok = reorder_second_tree(X, sign, o * nX, all.data() + (size_t)o * (size_t)nX, true);
+            ok = reorder_second_tree(X, sign, o * nX, all.data() + (size_t)o * (size_t)nX, from.data() + (size_t)o * (size_t)nX, true);
         }
         // ... and of the plain node array, for launch 1 (both in one allocation: the inlined copies first)
         const int nP = T.nT;
@@ -2001,7 +2008,7 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
             int sign[3] = {0, 0, 0};
             for (int a = 0; a < 3; a++)
                 if (axes & (1 << a)) sign[a] = (ord_copy(axes, a == 0 ? 1.f : -1.f, a == 1 ? 1.f : -1.f, a == 2 ? 1.f : -1.f) & o) ? 1 : -1;
-            ok = reorder_second_tree(Pn, sign, o * nP, allP.data() + (size_t)o * (size_t)nP, false);
+            ok = reorder_second_tree(Pn, sign, o * nP, allP.data() + (size_t)o * (size_t)nP, from.data() + all.size() + (size_t)o * (size_t)nP, false);
         }
         if (ok)
         {
@@ -2010,10 +2017,39 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
             HIPCHK(c, hipMemcpy((NodeQ*)d.tl2mem[15] + all.size(), allP.data(), allP.size() * sizeof(NodeQ), hipMemcpyHostToDevice));
             d.dpackedAny.tlasXO = (const NodeQ*)d.tl2mem[15]; d.dpackedAny.xStride = nX; d.dpackedAny.xAxes = axes;
             d.dpackedAny.tlasO = (const NodeQ*)d.tl2mem[15] + all.size(); d.dpackedAny.oStride = nP;
+            if (d.tl2mem[16]) { (void)hipFree(d.tl2mem[16]); d.tl2mem[16] = nullptr; }
+            HIPCHK(c, hipMalloc(&d.tl2mem[16], from.size() * sizeof(int)));
+            HIPCHK(c, hipMemcpy(d.tl2mem[16], from.data(), from.size() * sizeof(int), hipMemcpyHostToDevice));
+            d.ordX = all.size(); d.ordP = allP.size();
         }
     }
 #endif
-    d.any_ok = true;
+    d.any_ok = true; d.any_built = true;
+    return HRT_OK;
+}
+
+// After a scene update: the second tree keeps its topology and takes the new boxes (instance records and spheres are shared with the
+// tree in use and already updated), as long as the scene is still what the second tree is exact for -- every instance a fast sphere
+// with a regular box (the flags of its own finish pass), the tree in use a device refit / rebuild (unions of regular boxes: nested,
+// every instance once).  A new topology of the tree in use needs a new slot map.  Otherwise the walks go back to the tree in use.
+int refit_second_tree(hrt_ctx* c, DeviceState& d, bool newTopologyInUse, bool sceneStillFits)
+{
+    d.any_ok = false;
+    if (!d.any_built || !sceneStillFits || !c->own_in_world) return HRT_OK;
+    const TlasDevice& T2 = d.tl2;
+    if (d.tl.nTI != T2.nTI) return HRT_OK;
+    HIPCHK(c, tlas_finish(T2, d.stream));
+    HIPCHK(c, tlas_inflate(T2, d.stream));
+    int flags[4] = {1, 1, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(flags, T2.flags, sizeof(flags), hipMemcpyDeviceToHost, d.stream));
+    if (newTopologyInUse) HIPCHK(c, tlas_slot_map(d.tl.tlasInst, T2.tlasInst, (int*)d.tl2mem[17], (int*)d.tl2mem[14], T2.nTI, d.stream));
+    if (d.dpackedAny.tlasXO)
+    {
+        HIPCHK(c, tlas_refresh_copies((NodeQ*)d.tl2mem[15], T2.tlasX, (const int*)d.tl2mem[16], (int)d.ordX, d.stream));
+        HIPCHK(c, tlas_refresh_copies((NodeQ*)d.tl2mem[15] + d.ordX, T2.tlas, (const int*)d.tl2mem[16] + d.ordX, (int)d.ordP, d.stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(d.stream));
+    d.any_ok = flags[0] == 0 && flags[1] == 0;
     return HRT_OK;
 }
 
@@ -2064,7 +2100,7 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             HIPCHK(c, tlas_finish(T, d.stream));
             if ((rc = keep_as_base()) != HRT_OK) return rc;
         }
-        d.any_ok = false;                      // the second tree of boolean queries describes the scene as uploaded
+        d.any_ok = false;                      // the second tree describes the scene as it was: refit_second_tree brings it back below
         std::vector<void*> staged;
         struct StagedGuard {               // staging buffers of `mutate` are freed on every way out (their copies are ordered on d.stream)
             std::vector<void*>& v; hipStream_t st;
@@ -2103,6 +2139,8 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         d.dpacked.tlasX = inl ? (const NodeQ*)d.packed[6] : nullptr;
         d.dpacked.nTlasX = inl ? T.nT + T.nTI : 0;
         d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = kWNone;
+        // the second tree follows the scene (same topology, new boxes) or stands down
+        if ((rc = refit_second_tree(c, d, action == HRT_REBUILD_FORCE_REBUILD, !general && !c->feat_alpha && h_flags[1] == 0)) != HRT_OK) return rc;
         if (first)
         {
             float ms = 0.f;

@@ -244,6 +244,80 @@ def test_random_many_sphere_scenes_on_the_second_tree(orc, renderer, hostile):
 
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("hostile", [False, True])
+def test_random_many_sphere_scenes_with_sphere_updates(orc, renderer, hostile):
+    """256..600 one-sphere instances, then two rounds of moved / resized spheres under a random policy: the second tree keeps its
+    topology and follows (refit of its boxes, of its renumbered copies, a new slot map when the tree in use was rebuilt), or stands
+    down when a sphere is no longer a regular box (hostile).  Frames in four organisations against the oracle over the arrays the
+    device holds after each round."""
+    from tests import test_bvh_update_gpu as U
+    n_cases = max(4, N_CASES // 20)
+    failures = []
+    for case in range(n_cases):
+        rng = np.random.default_rng(SEED0 + 0x500000 + case + (0x40000 if hostile else 0))
+        n = int(rng.integers(256, 600))
+        ext = float(rng.choice([2.0, 5.0, 12.0]))
+        s = engine.Scene()
+        ids = []
+        if rng.random() < 0.7:
+            ids.append(s.add_sphere(scenes.sphere((0.0, -500.0, 0.0), 500.0, (0.6, 0.6, 0.6))))
+        for i in range(n):
+            c = (float(rng.uniform(-ext, ext)), float(rng.uniform(0.05, 0.4 * ext)), float(rng.uniform(-ext, ext)))
+            ids.append(s.add_sphere(scenes.sphere(c, float(rng.uniform(0.03, 0.12) * ext), tuple(float(v) for v in rng.uniform(0.1, 1.0, 3)),
+                                                  int(rng.choice([T.SHADING_LAMBERT] * 4 + [T.SHADING_MIRROR, T.SHADING_GLASS])), 1.5)))
+        for i in rng.permutation(len(ids)):
+            s.build_sphere_instance([ids[int(i)]])
+        s.rebuild_tlas()
+        renderer.commit(s)
+        arrs = s.arrays()
+        cfg = scenes.Config("fz3", 64, 40, 2, (float(rng.uniform(-1, 1)) * ext, float(rng.uniform(0.3, 1.0)) * ext, 2.2 * ext), (0.0, 0.15 * ext, 0.0),
+                            max_depth=int(rng.choice([2, 3, 5])))
+        po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc))
+        pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"))
+        for rnd in range(2):
+            policy = int(rng.choice([T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO]))
+            n_sph = len(arrs["spheres"])
+            first = int(rng.integers(0, n_sph)); cnt = int(rng.integers(1, n_sph - first + 1))
+            sp = arrs["spheres"].copy()
+            for f_ in "XYZ":
+                sp["center"][f_][first:first + cnt] += (rng.uniform(-0.3, 0.3, cnt) * ext * 0.2).astype(np.float32)
+            sp["radius"][first:first + cnt] *= rng.uniform(0.6, 1.3, cnt).astype(np.float32)
+            if rng.random() < 0.3:                    # twins: exactly equal distances on the refitted second tree too
+                a_, b_ = int(rng.integers(first, first + cnt)), int(rng.integers(first, first + cnt))
+                for f_ in "XYZ": sp["center"][f_][a_] = sp["center"][f_][b_]
+                sp["radius"][a_] = sp["radius"][b_]
+            if hostile:
+                for _ in range(int(rng.integers(1, 3))):
+                    i_ = first + int(rng.integers(0, cnt))
+                    if rng.random() < 0.5: sp["center"]["XYZ"[int(rng.integers(0, 3))]][i_] = rng.choice(np.array([NAN, INF, 1e30, 1e18, 0.0], np.float32))
+                    else: sp["radius"][i_] = rng.choice(np.array([0.0, -0.3, INF, NAN, 1e-30, 1e30], np.float32))
+            renderer.update_spheres(first, sp[first:first + cnt], policy)
+            arrs["spheres"] = sp
+            nodes, idx, inst = U._download(renderer)
+            arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = renderer.download_array("blasNodes"), inst, nodes, idx
+            desc, keep = T.scene_desc_from_arrays(arrs)
+            ref, oo = T.alloc_outputs(64, 40)
+            ost = orc.render_frame(desc, po_, oo, None)
+            bad = {}
+            for fl in (0, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS, T.FLAG_MEGAKERNEL):
+                renderer.reset_history()
+                got, og = T.alloc_outputs(64, 40)
+                st = renderer.render_params(pg_, og, flags=fl)
+                bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+                bad = {k: v for k, v in bad.items() if v}
+                if not bad and (fl & T.FLAG_COUNTERS) and st.k[1].as_dict() != ost.k[1].as_dict():
+                    bad = {"counters": 1}
+                if bad:
+                    failures.append((case, rnd, policy, fl, bad))
+                    break
+            if bad:
+                break
+        if len(failures) >= 5:
+            break
+    assert not failures, "cases that differ from the oracle (case, round, policy, flags, {array: elements}): %s" % failures
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("hostile", [False, True])
 def test_random_moves_through_the_device_update_path(orc, renderer, hostile):
     """Random scenes, then random instance moves (rigid, scaled, identity, a degenerate one now and then) under a random policy
     (refit / rebuild / auto) on the device: the instance records must be the oracle's, and the frame must be the oracle's frame on
