@@ -1706,14 +1706,14 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
     return HRT_OK;
 }
 
-// Scenes made of many fast-sphere instances (identity transform, one sphere): a second TLAS over the same instances, built on
-// the device with the LBVH of the scene updates, for the walks of the streamed pipeline (hrt_walker.hpp, ALT).  Any-hit walks and
+// Scenes made of many fast-sphere instances (identity transform, one sphere): a second TLAS over the same instances (topology from
+// host_sah_topology below, or the LBVH of the scene updates for very many instances; everything else by the device kernels of the
+// scene updates), for the walks of the streamed pipeline (hrt_walker.hpp, ALT) and launch 1.  Any-hit walks and
 // the last bounce's hit-or-miss walk do not depend on the tree at all; a closest-hit walk depends on it only through the order
 // in which instances at exactly the same distance are met, which the walker detects and resolves on the uploaded tree.  The
 // reference's median split cuts such a scene into slabs when one instance dominates the bounds (the ground sphere of BASELINE
 // config 3: 103 node visits per ray against 50).  Needs the uploaded tree to list every instance exactly once (the
-// second tree is built over "the instances").  Dropped again by the first scene update (the tree in use is then device-built
-// anyway, or its boxes have moved).
+// second tree is built over "the instances").  Scene updates refit it (refit_second_tree).
 constexpr int64_t kAnyTreeMinInstances = 256;
 
 // Topology of the second tree built on the HOST with a binned surface-area heuristic (16 bins on each axis over the box centres of
