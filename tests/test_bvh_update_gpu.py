@@ -708,6 +708,43 @@ def test_non_finite_spheres_through_the_update_path(orc, renderer, name):
     s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # leave the shared renderer in its default state
 
 
+def test_second_tree_stands_down_and_returns(orc, renderer):
+    """400 one-sphere instances (a second tree exists): an instance gets a translation (a general instance: the second tree cannot
+    describe the scene), later the identity again (it can), with sphere moves in between -- every frame against the oracle over the
+    tree the device holds, in the organisations that use the second tree and one that does not."""
+    cfg = scenes.Config("st", 0, 0, 0, (0.0, 2.2, 7.5), (0.0, 0.6, 0.0))
+    w, h, spp = 96, 60, 2
+    s = engine.Scene(); scenes.build_random_spheres(s, 400, seed=0xABCD, extent=3.0); renderer.commit(s)
+    so = orc.OrcScene(); scenes.build_random_spheres(so, 400, seed=0xABCD, extent=3.0)
+    arrs = so.arrays()
+
+    def check():
+        nodes, idx, inst = _download(renderer)
+        arrs["blasNodes"], arrs["instances"], arrs["tlasNodes"], arrs["tlasInstanceIndices"] = renderer.download_array("blasNodes"), inst, nodes, idx
+        desc, keep = T.scene_desc_from_arrays(arrs)
+        ref, ost = _oracle_render(orc, desc, cfg, w, h, spp)
+        for flags in (0, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS):
+            got, gst = _gpu_render(renderer, cfg, w, h, spp, flags)
+            H.assert_outputs_equal(ref, got)
+
+    check()
+    moved = scenes.rotation_affine("y", 0.0, 1.0, (0.3, 0.1, -0.2))
+    st = renderer.update_instances([7], [moved], T.REBUILD_FORCE_REFIT)
+    assert st.general_instances == 1
+    check()
+    sp = arrs["spheres"].copy()
+    sp["center"]["X"][1:] += np.float32(0.05)
+    renderer.update_spheres(1, sp[1:], T.REBUILD_AUTO); arrs["spheres"] = sp
+    check()
+    st = renderer.update_instances([7], [T.identity_affine()], T.REBUILD_FORCE_REFIT)
+    assert st.general_instances == 0
+    check()
+    sp = sp.copy(); sp["radius"][1:] *= np.float32(0.9)
+    renderer.update_spheres(1, sp[1:], T.REBUILD_FORCE_REBUILD); arrs["spheres"] = sp
+    check()
+    s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # leave the shared renderer in its default state
+
+
 def test_update_spheres_errors(renderer):
     s = engine.Scene(); scenes.build_config2(s); renderer.commit(s)
     n = len(s.arrays()["spheres"])
