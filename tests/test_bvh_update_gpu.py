@@ -708,10 +708,14 @@ def test_non_finite_spheres_through_the_update_path(orc, renderer, name):
     s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)          # leave the shared renderer in its default state
 
 
-def test_second_tree_stands_down_and_returns(orc, renderer):
+@pytest.mark.parametrize("slots", [1, 3])
+def test_second_tree_stands_down_and_returns(orc, renderer, slots):
     """400 one-sphere instances (a second tree exists): an instance gets a translation (a general instance: the second tree cannot
     describe the scene), later the identity again (it can), with sphere moves in between -- every frame against the oracle over the
-    tree the device holds, in the organisations that use the second tree and one that does not."""
+    tree the device holds, in the organisations that use the second tree and one that does not.  slots = 3: one context over three
+    device slots on the one GPU (every slot keeps and refits a second tree of its own)."""
+    if slots > 1:
+        renderer = engine.RTRenderer([0] * slots)
     cfg = scenes.Config("st", 0, 0, 0, (0.0, 2.2, 7.5), (0.0, 0.6, 0.0))
     w, h, spp = 96, 60, 2
     s = engine.Scene(); scenes.build_random_spheres(s, 400, seed=0xABCD, extent=3.0); renderer.commit(s)
