@@ -200,7 +200,8 @@ typedef struct hrt_bvh_update_stats {
     float   growth_refit;     /* after the refit: geometric mean over the nodes of area / area at the last build (0: no refit) */
     float   growth_final;     /* the same for the tree now in use (1 after a rebuild)                          */
     float   sah_cost;         /* of the tree now in use: sum(area x (leaf ? count : 1)) / area(root)            */
-    float   device_ms;        /* HIP-event time of the device work on device slot 0                            */
+    float   device_ms;        /* HIP-event time of the device work on device slot 0 (tree in use; the library's second tree
+                                 over many one-sphere instances is refitted after it, about as long again)    */
     int32_t blas_action;      /* hrt_scene_update_positions: what happened to the mesh BLASes (0 none, refit, rebuild) */
     float   blas_growth;      /* ... and the growth of their node boxes after the refit (0: not measured)       */
 } hrt_bvh_update_stats;
