@@ -1889,7 +1889,7 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
 }
 int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce)
 {
-    d.any_ok = false;
+    d.any_ok = false; d.any_built = false;
 #ifdef HRT_NO_ANY_TREE             // A/B
     return HRT_OK;
 #endif
