@@ -530,14 +530,25 @@ def test_random_call_sequences(orc, hrt_lib):
         try:
             w = h = 0
             so = desc = None
+            moved_spheres, keep2 = False, None
             A = B = None
             frame = int(rng.integers(0, 50))
             log = []
             for step in range(int(rng.integers(8, 20))):
-                op = rng.choice(["commit", "frame", "frame", "frame", "async", "move", "reset", "limit", "resize"]) if so is not None else "commit"
+                op = rng.choice(["commit", "frame", "frame", "frame", "async", "move", "spheres", "reset", "limit", "resize"]) if so is not None else "commit"
+                if op == "move" and moved_spheres: op = "frame"       # (the oracle's scene object no longer holds the spheres the device has)
                 log.append(str(op))
                 if op == "commit":
                     ops, fr = _scene_recipe(int(rng.integers(0, 2 ** 31)))
+                    moved_spheres, keep2 = False, None
+                    if rng.random() < 0.3:      # 260..400 one-sphere instances: the library keeps a second tree for such a scene, across the calls below
+                        ext = float(rng.choice([2.0, 5.0]))
+                        ops = [("sphere", (0.0, -500.0, 0.0), 500.0, (0.6, 0.6, 0.6), T.SHADING_LAMBERT, 1.0, True)]
+                        for _ in range(int(rng.integers(260, 400))):
+                            ops.append(("sphere", (float(rng.uniform(-ext, ext)), float(rng.uniform(0.05, 0.4 * ext)), float(rng.uniform(-ext, ext))), float(rng.uniform(0.03, 0.12) * ext),
+                                        tuple(float(v) for v in rng.uniform(0.1, 1.0, 3)), int(rng.choice([T.SHADING_LAMBERT] * 4 + [T.SHADING_MIRROR, T.SHADING_GLASS])), 1.5, True))
+                        fr = dict(fr, origin=(float(rng.uniform(-1, 1)) * ext, float(rng.uniform(0.3, 1.0)) * ext, 2.2 * ext), lookat=(0.0, 0.15 * ext, 0.0), vfov=60.0)
+                        log[-1] += " many"
                     so = orc.OrcScene(); _apply(so, ops)
                     s = engine.Scene(); _apply(s, ops)
                     r.commit(s); desc = so.desc()
@@ -551,6 +562,27 @@ def test_random_call_sequences(orc, hrt_lib):
                     if A is not None: A, B = H.new_reservoirs(len(A["res_m"]), 1), H.new_reservoirs(len(A["res_m"]), 1)
                 elif op == "limit":
                     r.set_workspace_limit(int(rng.choice([0, w * h + 3, 2 * w * h + 1, 10 ** 9])))
+                elif op == "spheres":
+                    arrs2 = so.arrays() if keep2 is None else keep2[0]
+                    sp = arrs2["spheres"].copy()
+                    n_sph = len(sp)
+                    first = int(rng.integers(0, n_sph)); cnt = int(rng.integers(1, n_sph - first + 1))
+                    for f_ in "XYZ":
+                        sp["center"][f_][first:first + cnt] += rng.uniform(-0.2, 0.2, cnt).astype(np.float32)
+                    sp["radius"][first:first + cnt] *= rng.uniform(0.7, 1.2, cnt).astype(np.float32)
+                    try:
+                        r.update_spheres(first, sp[first:first + cnt], int(rng.choice([T.REBUILD_FORCE_REFIT, T.REBUILD_FORCE_REBUILD, T.REBUILD_AUTO])))
+                    except engine.HrtError as e:
+                        if "refit" not in str(e): raise
+                        log[-1] += " (refused)"
+                        continue
+                    arrs2 = dict(arrs2); arrs2["spheres"] = sp
+                    nodes, idx, inst = U._download(r)
+                    arrs2["blasNodes"], arrs2["instances"], arrs2["tlasNodes"], arrs2["tlasInstanceIndices"] = r.download_array("blasNodes"), inst, nodes, idx
+                    arrs2["triPrimIdx"], arrs2["spherePrimIdx"] = r.download_array("triPrimIdx"), r.download_array("spherePrimIdx")
+                    desc, k2 = T.scene_desc_from_arrays(arrs2)
+                    keep2 = (arrs2, k2)
+                    moved_spheres = True
                 elif op == "move":
                     n_inst = len(so.arrays()["instances"])
                     ids = sorted(set(int(v) for v in rng.integers(0, n_inst, int(rng.integers(1, min(n_inst, 4) + 1)))))
