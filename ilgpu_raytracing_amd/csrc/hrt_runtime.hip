@@ -2758,6 +2758,41 @@ extern "C" int hrt_debug_pt_stats(unsigned long long* out64)
 }
 #endif
 
+// ---- host-only test hooks of the second tree (include/hip_raytrace.h)
+extern "C" {
+
+int hrt_debug_second_tree_topology(const hrt_instance* instances, int32_t n, int32_t* order, int32_t* link, int32_t* skip, int32_t* count,
+                                   int32_t* parent, int32_t* n_nodes)
+try {
+    if (!instances || n < 1 || !order || !link || !skip || !count || !parent || !n_nodes) return HRT_ERR_INVALID_ARG;
+    std::vector<hrt_instance> inst(instances, instances + n);
+    SahTopology t;
+    host_sah_topology(inst, t);
+    *n_nodes = (int32_t)t.nodes.size();
+    std::memcpy(order, t.order.data(), (size_t)n * 4);
+    for (size_t i = 0; i < t.nodes.size(); i++)
+    {
+        const int lo = __builtin_bit_cast(int, t.nodes[i].lo.w), hi = __builtin_bit_cast(int, t.nodes[i].hi.w);
+        link[i] = lo; skip[i] = hi & kEnd; count[i] = (int32_t)((unsigned)hi >> 28); parent[i] = t.parent[i];
+    }
+    return HRT_OK;
+}
+catch (...) { return on_exception(nullptr, "hrt_debug_second_tree_topology"); }
+
+int hrt_debug_second_tree_reorder(const float* records, int32_t n_records, const int32_t* sign, int32_t base, int32_t inlined, float* out_records, int32_t* from)
+try {
+    if (!records || n_records < 1 || !sign || !out_records || !from) return HRT_ERR_INVALID_ARG;
+    std::vector<NodeQ> X((size_t)n_records), out((size_t)n_records);
+    std::memcpy(X.data(), records, (size_t)n_records * sizeof(NodeQ));
+    const int sg[3] = {sign[0], sign[1], sign[2]};
+    if (!reorder_second_tree(X, sg, base, out.data(), from, inlined != 0)) return HRT_ERR_INVALID_ARG;
+    std::memcpy(out_records, out.data(), (size_t)n_records * sizeof(NodeQ));
+    return HRT_OK;
+}
+catch (...) { return on_exception(nullptr, "hrt_debug_second_tree_reorder"); }
+
+} // extern "C"
+
 #ifdef HRT_WALK_STATS
 // variant builds only (tools/walk_stats.py): read and clear the walker's phase statistics of the current device
 extern "C" int hrt_debug_walk_stats(unsigned long long* out48)

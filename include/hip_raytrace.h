@@ -293,6 +293,20 @@ int  hrt_math_probe(hrt_ctx* ctx, int fn, int n, const float* x, const float* y,
  * [2^-96, +inf]).  *mismatches = number of differing results (0 expected), *first_bad (may be NULL) = bits of the smallest one. */
 int  hrt_math_exhaustive(hrt_ctx* ctx, int which, uint64_t* mismatches, uint32_t* first_bad);
 
+/* test hooks, host code only (no device, no context): what hrt_scene_upload computes on the host for the SECOND tree of a scene of
+ * many one-sphere instances.
+ * hrt_debug_second_tree_topology: the binned-SAH topology over the world bounds of n instances, in walk order.  order[n]: instance
+ *   of every leaf slot; per node i < *n_nodes (arrays of capacity 2 n): link[i] = first slot of a leaf / index of the first child,
+ *   skip[i] = next node when node i is missed (0x0FFFFFFF: none), count[i] = instances of a leaf (0: inner node), parent[i].
+ * hrt_debug_second_tree_reorder: the renumbering of a node array (records of 8 floats: lo.xyz, link word, hi.xyz, skip word with
+ *   the count in its top four bits; inlined != 0: every leaf is followed by one record per instance, count field 15) for rays
+ *   whose direction has the signs sign[3] (+1 / -1 / 0: builder's order along that axis); links of the result are offset by base;
+ *   from[i] = record of the input at position i.  Returns 0, or HRT_ERR_INVALID_ARG if the input is not such a tree. */
+int  hrt_debug_second_tree_topology(const hrt_instance* instances, int32_t n, int32_t* order, int32_t* link, int32_t* skip,
+                                    int32_t* count, int32_t* parent, int32_t* n_nodes);
+int  hrt_debug_second_tree_reorder(const float* records, int32_t n_records, const int32_t* sign, int32_t base, int32_t inlined,
+                                   float* out_records, int32_t* from);
+
 int  hrt_device_count(void);                    /* visible HIP devices, <0 on error */
 const char* hrt_version(void);
 
