@@ -77,6 +77,46 @@ def test_boolean_queries_on_the_second_tree_change_nothing(orc, hrt_lib):
         r.close()
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("count", [40000, 270000])
+def test_second_tree_of_a_big_scene(orc, hrt_lib, count):
+    """40 001 instances: host SAH topology, four renumbered copies of 3 MB each; 270 001: beyond the host builder's limit, the
+    device's LBVH topology, copies of 26 MB each (the copies need not fit the L2).  A small frame in the organisations that use
+    the second tree, a sphere update with a refit, and the frame again, against the oracle."""
+    ext = 20.0 * (count / 10000.0) ** 0.5
+    cfg = scenes.Config("big", 0, 0, 0, (0.0, 6.0, 26.0), (0.0, 1.0, 0.0))
+    w, h, spp = 96, 54, 2
+    so = orc.OrcScene(); scenes.build_random_spheres(so, count, extent=ext)
+    s = engine.Scene(); scenes.build_random_spheres(s, count, extent=ext)
+    r = engine.RTRenderer([0])
+    try:
+        r.commit(s)
+        arrs = so.arrays()
+        for rnd in range(2):
+            if rnd == 1:
+                sp = arrs["spheres"].copy()
+                sp["center"]["X"][1:] += np.float32(0.1); sp["radius"][1::7] *= np.float32(1.2)
+                r.update_spheres(1, sp[1:], T.REBUILD_FORCE_REFIT)
+                arrs["spheres"] = sp
+                for k in ("blasNodes",): arrs[k] = r.download_array(k)
+                nodes, idx, inst, cnt = r.download_tlas()
+                arrs["tlasNodes"] = np.frombuffer(nodes, dtype=T.np_dtype(T.BvhNode), count=cnt[0]).copy()
+                arrs["tlasInstanceIndices"] = np.frombuffer(idx, dtype=np.int32, count=cnt[1]).copy()
+                arrs["instances"] = np.frombuffer(inst, dtype=T.np_dtype(T.InstanceRecord), count=cnt[2]).copy()
+            desc, keep = T.scene_desc_from_arrays(arrs)
+            po = scenes.frame_params(cfg, *H.host_funcs("orc", orc), width=w, height=h, spp=spp)
+            ref, oo = T.alloc_outputs(w, h)
+            orc.render_frame(desc, po, oo, None)
+            p = _params(cfg, w, h, spp)
+            for flags in (0, T.FLAG_STREAMED):
+                r.reset_history()
+                got, og = T.alloc_outputs(w, h)
+                r.render_params(p, og, flags=flags)
+                H.assert_outputs_equal(ref, got)
+    finally:
+        r.close()
+
+
 def test_equal_distance_instances_on_the_second_tree(orc, hrt_lib):
     """Closest-hit walks over the second tree must still name the instance the UPLOADED tree meets first when several lie at exactly
     the same distance (hrt_walker.hpp, kTies).  400 fast-sphere instances of which 120 are exact duplicates (same centre and radius)
