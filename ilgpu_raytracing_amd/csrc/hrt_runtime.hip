@@ -1721,8 +1721,12 @@ constexpr int64_t kAnyTreeMinInstances = 256;
 // split is halved), in the numbering the walkers want (walk order: a node's first child follows it).
 // Only WHICH instances share a subtree is decided here -- boxes, leaf-slot records, the inlined layout and the slack are the
 // device's (tlas_finish, tlas_inflate), exactly as for the LBVH the scene updates build.  Against that LBVH: 6-10 % fewer node
-// visits per ray on config 3 (tools/tree_order_model.py); the scene updates keep the LBVH, which is built in 0.3 ms.
-constexpr int64_t kHostSahMaxInstances = 1 << 18;
+// visits per ray on config 3 (tools/tree_order_model.py); the scene updates keep the LBVH, which is built in 0.3 ms, and so do
+// scenes of more than two million instances.
+#ifndef HRT_SAH_MAX_LOG2            // A/B (300 001 instances: LBVH topology 12.3 ms per frame and 0.29 s per upload, SAH 11.5 ms and 0.38 s)
+#define HRT_SAH_MAX_LOG2 21
+#endif
+constexpr int64_t kHostSahMaxInstances = (int64_t)1 << HRT_SAH_MAX_LOG2;
 constexpr int kSahLeaf = 4;       // instances per leaf at most (config 3, path stage + launch 1: 15.66 / 15.37 / 15.39 / 15.41 ms for 2 / 3 / 4 / 6)
 struct SahTopology { std::vector<int32_t> order; std::vector<NodeQ> nodes; std::vector<int> parent, nchild; int leaves = 0; };
 void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)

@@ -80,8 +80,8 @@ def test_boolean_queries_on_the_second_tree_change_nothing(orc, hrt_lib):
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("count", [40000, 270000])
 def test_second_tree_of_a_big_scene(orc, hrt_lib, count):
-    """40 001 instances: host SAH topology, four renumbered copies of 3 MB each; 270 001: beyond the host builder's limit, the
-    device's LBVH topology, copies of 26 MB each (the copies need not fit the L2).  A small frame in the organisations that use
+    """40 001 instances: four renumbered copies of 3 MB each; 270 001: copies of 26 MB each (they need not fit the L2).  A small
+    frame in the organisations that use
     the second tree, a sphere update with a refit, and the frame again, against the oracle."""
     ext = 20.0 * (count / 10000.0) ** 0.5
     cfg = scenes.Config("big", 0, 0, 0, (0.0, 6.0, 26.0), (0.0, 1.0, 0.0))
