@@ -173,6 +173,7 @@ FLAG_MEGAKERNEL = 16
 FLAG_STREAMED = 32
 FLAG_PRIMARY_ONLY = 64
 FLAG_EXCHANGED = 128
+FLAG_TREELETS = 256
 
 SHADING_LAMBERT, SHADING_MIRROR, SHADING_GLASS = 0, 1, 2
 BLAS_SPHERESET, BLAS_TRIMESH = 1, 2

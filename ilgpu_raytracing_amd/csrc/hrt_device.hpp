@@ -809,11 +809,8 @@ HRT_D Res restir_candidates(const FrameK& k, const DGBuffer& gb, const DReservoi
     Res r; r.wi = mk3(0.f, 0.f, 0.f); r.w = 0.f; r.wSum = 0.f; r.m = 0; r.lightId = 0;
     // kept rolled: unrolled 8x the candidate body alone is ~3000 instructions (24 KB), a third of the instruction cache
     // two CUs share; the loop-carried state is a handful of registers
-#ifndef HRT_ABL_CAND
-#define HRT_ABL_CAND 8
-#endif
 #pragma unroll 1
-    for (int i = 0; i < HRT_ABL_CAND; i++)
+    for (int i = 0; i < 8; i++)
     {
         F3 wi = sample_hemisphere_cosine(fr, rng);
         float nl = hrt_fmax(0.f, dot(n, wi));
@@ -1028,11 +1025,7 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                         {
                             PSTAT(4);
                             Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
-#ifdef HRT_ABL_NOSHADOW
-                            if (sray.o.x != 12345.f)
-#else
                             if (!tr.template occluded<COUNT>(sray, 1e29f, C))
-#endif
                             {
                                 float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
                                 F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
@@ -1067,9 +1060,6 @@ HRT_D void path_trace_pixel(const TR& tr, const FrameK& k, const DGBuffer& gb, c
                 {   // TraceNext :659-671 -- the one closest-hit site of the bounce loop
                     PSTAT(5);
                     Hit h;
-#ifdef HRT_ABL_CLOSEST2
-                    { Hit h2; Ray r2 = ray; r2.o.x += 1e-3f; if (tr.template closest<COUNT>(r2, h2, C)) T.x += h2.t * 1e-30f; }
-#endif
                     if (!tr.template closest<COUNT>(ray, h, C)) { Li = Li + T * sky(k, ray.d); ended = true; }
                     else
                     {

@@ -22,9 +22,13 @@
 #include "hrt_device.hpp"
 #include "hrt_trace_packed.hpp"
 #include "hrt_wavefront.hpp"
+#include "hrt_walker_tl.hpp"
 #include "hrt_bvh.hpp"
 #include "hrt_post.hpp"
 #include "../../include/hip_raytrace.h"
+#ifdef HRT_TEST_HOOKS
+#include "../../include/hrt_test_hooks.h"
+#endif
 
 using namespace hrt;
 
@@ -205,25 +209,103 @@ hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, Wf
     C.flush(counters);
 }
 
-#ifdef HRT_TUNING
-template <int FEAT>
-__global__ void __launch_bounds__(256, 4)
-hrt_wf_walkw_shadow_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int vsel, int depth, int chained)
+// ---------------------------------------------------------------------------------------
+// Treelet-queued walks (hrt_walker_tl.hpp): production frames of scenes with big triangle meshes.
+// PHASE 0 fresh rays of the path ranges; PHASE 1 one round over the rays binned by treelet, a span of the binned list per
+// workgroup, each treelet of the span staged once in LDS; PHASE 2 clean-up of what is still suspended, from global memory.
+// ---------------------------------------------------------------------------------------
+template <int FEAT, bool ANY, bool EXISTS, int LT, int PHASE>
+__global__ void __launch_bounds__(256, PHASE == 1 ? 2 : 4)
+hrt_tl_walk_kernel(TracerPackedT<FEAT> tr, DTreelets T, TlQueues Q, WfBuffers W, int depth, int histBins, int tlRegion, int round)
 {
-    int own = -1;
-    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walkw_shadow_wave<FEAT>(tr, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own);
+    const TlShared sh = tl_shared(tlRegion, T.redLds, histBins);
+    {   // the top of the reduced tree stays in LDS for the whole kernel
+        float4* red = const_cast<float4*>(sh.red);
+        const float4* src = reinterpret_cast<const float4*>(T.red);
+        for (int i = threadIdx.x; i < T.redLds * 2; i += 256) red[i] = src[i];
+        for (int i = threadIdx.x; i < histBins; i += 256) sh.hist[i] = 0;
+    }
+    __syncthreads();
+    auto fetch = [&](int i, Ray& r) {
+        if (ANY)
+        {
+            const float4 qa = W.SQ.ld4(SQ_A, i), qb = W.SQ.ld4(SQ_B, i);
+            r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
+            return true;
+        }
+        const float4 qa = W.R.ld4(RQ_A, i), qb = W.R.ld4(RQ_B, i);
+        if (__float_as_int(qb.z) & RF_DEAD) return false;
+        r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
+        return true;
+    };
+    auto done = [&](int i, const WalkResult& res) {
+        if (ANY) { if (!res.occluded) W.SQ.sti(S_VIS, i, 1); }
+        else W.R.st4(RQ_H, i, mkq(res.t, res.tObj, __int_as_float(res.slot), __int_as_float(res.prim)));
+    };
+    if (PHASE != 1)
+    {
+        RangeGrab G; G.init(PHASE == 0 ? W.grab + (depth * 2 + (ANY ? 0 : 1)) * 8 : Q.misc + 8, W.nRanges, -1);
+        const int* cnt = (ANY ? W.cntS : W.cntA) + (size_t)depth * W.nRanges;
+        walk_tl<FEAT, ANY, EXISTS, LT, PHASE>(tr, T, Q, sh, histBins, Treelet{},
+            [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
+            fetch, done, PHASE == 0 ? 0 : 7);
+    }
+    else
+    {
+        const int M = Q.misc[0];
+        const int G = (int)gridDim.x;
+        int span = (M + G - 1) / G;
+        if (span < kTlSpanMin) span = kTlSpanMin;
+        const long long p0 = (long long)blockIdx.x * span;
+        const int p1 = (int)(p0 + span < (long long)M ? p0 + span : (long long)M);
+        int p = p0 < M ? (int)p0 : M;
+        while (p < p1)
+        {
+            int lo = 0, hi = T.nTl;                           // offs[lo] <= p < offs[hi]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (Q.offs[mid] <= p) lo = mid; else hi = mid; }
+            const Treelet tlc = T.tl[lo];
+            const int segEnd = Q.offs[lo + 1] < p1 ? Q.offs[lo + 1] : p1;
+            __syncthreads();                                   // every wave has left the treelet staged before
+#ifdef HRT_TL_STATS
+            const long long tStage0 = (long long)__builtin_readcyclecounter();
+#endif
+            {
+                const int nN = 2 * (tlc.nodeHi - tlc.nodeLo), nT = 3 * (tlc.triHi - tlc.triLo);
+                const float4* sn = reinterpret_cast<const float4*>(tr.P.blas + tlc.nodeLo);
+                const float4* st = reinterpret_cast<const float4*>(tr.P.ftri + tlc.triLo);
+                for (int i = threadIdx.x; i < nN; i += 256) sh.tl[i] = sn[i];
+                for (int i = threadIdx.x; i < nT; i += 256) sh.tl[nN + i] = st[i];
+                if (threadIdx.x == 0) sh.misc[0] = p;
+            }
+            __syncthreads();
+#ifdef HRT_TL_STATS
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_tl_stats[round < 6 ? round : 6][ANY ? 0 : 1][12], (unsigned long long)((long long)__builtin_readcyclecounter() - tStage0));
+#endif
+            walk_tl<FEAT, ANY, EXISTS, LT, 1>(tr, T, Q, sh, histBins, tlc,
+                [&](int& base, int& n) {
+                    int b = 0;
+                    if ((threadIdx.x & 63) == 0) b = atomicAdd(&sh.misc[0], 64);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= segEnd) return false;
+                    base = b; n = segEnd - b < 64 ? segEnd - b : 64;
+                    return true;
+                },
+                fetch, done, round < 6 ? round : 6);
+            p = segEnd;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < histBins; b += 256) { const int v = sh.hist[b]; if (v) atomicAdd(&Q.hist[b], v); }
 }
 
-template <int FEAT>
-__global__ void __launch_bounds__(256, 4)
-hrt_wf_walkw_closest_kernel(TracerPackedT<FEAT> tr, WfBuffers W, int depth, int chained)
+__global__ void __launch_bounds__(1024)
+hrt_tl_scan_kernel(TlQueues Q, int nTl) { tl_scan_block(Q, nTl); }
+
+__global__ void __launch_bounds__(256)
+hrt_tl_scatter_kernel(TlQueues Q, int nTl, const int* cnt, int nRanges)
 {
-    int own = -1;
-    if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
-    wf_walkw_closest_wave<FEAT>(tr, W, depth, W.grab + (depth * 2 + 1) * 8, own);
+    tl_scatter_block(Q, nTl, cnt, nRanges, wf_range(nRanges));
 }
-#endif
 
 template <int FEAT, bool COUNT>
 __global__ void __launch_bounds__(256)
@@ -268,6 +350,7 @@ hrt_bilinear_upsample_kernel(const int32_t* src, int srcW, int srcH, int32_t* ds
     if (i < dstW * dstH) bilinear_upsample_pixel(src, srcW, srcH, dst, dstW, dstH, i);
 }
 
+#ifdef HRT_TEST_HOOKS
 // exactness probe: evaluates include/hrt_math.h on the device (tests compare with the oracle's bits)
 __global__ void hrt_math_probe_kernel(int fn, int n, const float* x, const float* y, float* out)
 {
@@ -314,12 +397,15 @@ __global__ void hrt_math_exhaustive_kernel(int which, unsigned long long* mismat
     if (bad) atomicAdd(mismatches, bad);
 }
 
+#endif // HRT_TEST_HOOKS
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
 namespace {
 
 thread_local std::string g_create_error;
+TreeletLimits g_treelet_limits;              // shipped values unless a test lowered them (hrt_debug_set_treelet_limits)
 
 #ifndef HRT_BATCH_LANES
 #define HRT_BATCH_LANES 2
@@ -357,6 +443,12 @@ struct DeviceState {
     BlasDevice bl{};                           // triangle-mesh BLAS maintenance after vertex updates
     void* blaux[12] = {};                      // parent, nchild, subend, orig, arrive, ids of the TriMesh instances, kind, ids of the SphereSet instances, sa, saBase, growPartial, grow
     int n_mesh_inst = 0, n_sphere_inst = 0;
+    // treelets of the big triangle-mesh BLASes (hrt_treelets.hpp) and the queues of the treelet walker, per batch lane and walk kind (0 shadow, 1 closest)
+    void* tlmem[3] = {};                       // reduced trees, treelet table, BLAS root -> reduced root
+    DTreelets dtl{};
+    bool tl_ok = false;                        // the treelets describe the BLASes as they are now (a vertex update or BLAS rebuild drops them)
+    void* tlq_mem[kMaxLanes] = {}; size_t tlq_bytes[kMaxLanes] = {};
+    int max_lds = 65536;                       // LDS a workgroup may ask for
     bool blas_base_valid = false;              // saBase holds the node areas of the mesh BLASes as they were last built
     // presentation (TAAU history + display-size colour), device slot 0 only
     int32_t *present_color = nullptr, *taa_hist_color = nullptr, *taa_hist_obj = nullptr;
@@ -369,7 +461,6 @@ struct DeviceState {
     hipStream_t laneStream[kMaxLanes][2] = {};  // lanes >= 1: main and side stream (lane 0 uses stream / stream2)
     hipEvent_t evLane[kMaxLanes][3] = {};      // per lane: fork, join, resolve done
     hipEvent_t evStage = nullptr;
-    int* wf_ovf = nullptr;                     // wide walker stack overflow area (allocated on first use)
     float* split_mem = nullptr; size_t split_floats = 0;    // fused kernel in sample groups: per-sample radiance + staged reservoirs
     // per-pixel buffers, full image size on every device (rows outside the tile stay untouched)
     int64_t nPix = 0;
@@ -390,7 +481,6 @@ struct hrt_ctx {
     bool scene_ready = false;
     bool packed_ok = false;                    // false: scene exceeds the packed layout's limits -> TracerRef
     int packed_feat = 3;                       // TracerPackedT<FEAT> variant of the committed scene
-    int wide_depth = 0;                        // > 0: the 4-wide collapse exists; stack bound of the wide walker = 3 * wide_depth + 2
     int flat_leaves = 0;                       // > 0: TLAS leaves of a fast-sphere-only scene that fits TracerFlat
     bool own_in_world = false;                 // PackedHost::own_in_world of the uploaded scene
     bool small_scene = false;                  // <= kSmallSceneNodes BVH nodes: the walk is ALU-bound and L1-resident -> megakernel
@@ -513,6 +603,7 @@ void free_present(DeviceState& d)
 
 void free_workspace(DeviceState& d)
 {
+    for (int j = 0; j < kMaxLanes; j++) { if (d.tlq_mem[j]) (void)hipFree(d.tlq_mem[j]); d.tlq_mem[j] = nullptr; d.tlq_bytes[j] = 0; }
     for (int j = 0; j < kMaxLanes; j++)
     {
         if (d.wf_mem[j]) (void)hipFree(d.wf_mem[j]);
@@ -521,8 +612,6 @@ void free_workspace(DeviceState& d)
     }
     if (d.wf_accum) (void)hipFree(d.wf_accum);
     d.wf_accum = nullptr; d.wf_accum_floats = 0;
-    if (d.wf_ovf) (void)hipFree(d.wf_ovf);
-    d.wf_ovf = nullptr;
     if (d.split_mem) (void)hipFree(d.split_mem);
     d.split_mem = nullptr; d.split_floats = 0;
 }
@@ -538,6 +627,8 @@ void free_scene(DeviceState& d)
     d.tlscratch = nullptr; d.tl = TlasDevice{}; d.tlas_base_valid = false; d.tlas_lbvh = false;
     for (int i = 0; i < 12; i++) { if (d.blaux[i]) (void)hipFree(d.blaux[i]); d.blaux[i] = nullptr; }
     d.bl = BlasDevice{}; d.n_mesh_inst = 0; d.n_sphere_inst = 0; d.blas_base_valid = false;
+    for (int i = 0; i < 3; i++) { if (d.tlmem[i]) (void)hipFree(d.tlmem[i]); d.tlmem[i] = nullptr; }
+    d.dtl = DTreelets{}; d.tl_ok = false;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -551,9 +642,6 @@ struct PackedHost {
     std::vector<FInst> finst;
     std::vector<FTri> ftri;
     std::vector<NodeQ> tlasX; // FEAT 0: TLAS with instance records inlined after their leaf (walker)
-    std::vector<WNode> wide;  // 4-wide collapse of the TLAS and of every BLAS range (wide walker)
-    int wide_tlas_root = kWNone;
-    int wide_depth = 0;       // wide levels of the TLAS + of the deepest BLAS (stack bound of the wide walker); 0: not built
     int n_tlasX = 0;          // records in tlasX (0: not built)
     int n_flat = 0;           // leaves in `flat` (0: scene does not qualify)
     std::vector<int32_t> parent, nchild;     // TLAS, packed numbering: parent of a node (-1: none), children of an inner node
@@ -564,6 +652,7 @@ struct PackedHost {
     std::vector<int32_t> sphereInst;                         // ids of the SphereSet instances whose BLAS is maintained
     std::vector<int32_t> meshInst;                           // ids of the TriMesh instances whose BLAS is maintained
     std::vector<MeshJob> meshJobs;                           // the same, with what a device-side rebuild of the BLAS needs
+    std::vector<std::pair<int64_t, int64_t>> meshRanges;     // node ranges of the maintained triangle-mesh BLASes (walk order): candidates for treelets
     bool blas_rebuild_ok = true;                             // every mesh's leaves list their triangles in one region of triPrimIdx
     bool blas_refit_ok = true;                               // every TriMesh BLAS can be refitted on the device
     bool refit_ok = true;     // the TLAS can be refitted bottom-up on the device (hrt_bvh.hpp)
@@ -797,6 +886,7 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
                 if (kind != 1 && kind != 2) { if (kind != 0) out.blas_refit_ok = false; continue; }               // shared between a mesh and a sphere set, or of an unknown type
                 if (reach != (int32_t)(r.second - r.first)) { out.blas_refit_ok = false; continue; }              // unreachable nodes or builder numbering
                 for (int64_t k = r.first; k < r.second; k++) out.bkind[(size_t)k] = kind;
+                if (kind == 1) out.meshRanges.push_back(r);
                 out.max_range[kind] = std::max(out.max_range[kind], (int)(r.second - r.first));
                 auto cntq = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, out.blas[(size_t)i].hi.w) >> 28); };
                 auto skipq = [&](int64_t i) { return __builtin_bit_cast(int, out.blas[(size_t)i].hi.w) & kEnd; };
@@ -912,85 +1002,6 @@ std::string validate_and_pack(const hrt_scene_desc* s, PackedHost& out)
         o.v1 = mkf4(b.X, b.Y, b.Z, bits_f(mi));
         o.v2 = mkf4(c.X, c.Y, c.Z, bits_f(fl));
     }
-    // ---- 4-wide collapse for the wide walker: every inner node takes its grandchildren (children where a child is a leaf),
-    // kept in walk order; nodes are numbered depth-first so a subtree is contiguous.  Returns the reference of the range's root.
-    int wideDepthMax = 0;
-    auto collapse = [&](const std::vector<NodeQ>& nodes, int64_t rootIdx, int& depthOut) -> int {
-        auto cnt_of = [&](int64_t i) { return (int)((unsigned)__builtin_bit_cast(int, nodes[(size_t)i].hi.w) >> 28); };
-        auto left_of = [&](int64_t i) { return (int64_t)(__builtin_bit_cast(int, nodes[(size_t)i].lo.w) & kEnd); };
-        auto skip_of = [&](int64_t i) { return (int64_t)(__builtin_bit_cast(int, nodes[(size_t)i].hi.w) & kEnd); };
-        depthOut = 0;
-        if (cnt_of(rootIdx) > 0) return ~(int)rootIdx;                 // the whole tree is one leaf
-        struct Job { int64_t node; int wide; int depth; };
-        std::vector<Job> jobs;
-        const int rootWide = (int)out.wide.size();
-        out.wide.emplace_back();
-        jobs.push_back({rootIdx, rootWide, 1});
-        while (!jobs.empty())
-        {
-            const Job jb = jobs.back(); jobs.pop_back();
-            depthOut = std::max(depthOut, jb.depth);
-            int64_t kids[4]; int nk = 0;
-            const int64_t l = left_of(jb.node);
-            if (l == kEnd) { out.wide[(size_t)jb.wide] = WNode{}; out.wide[(size_t)jb.wide].ref = int4{kWNone, kWNone, kWNone, kWNone}; continue; }   // inner node without children
-            const int64_t r = skip_of(l);
-            for (int64_t c : {l, r})
-            {
-                if (c == kEnd) continue;
-                const int64_t cl = cnt_of(c) > 0 ? kEnd : left_of(c);
-                if (cnt_of(c) > 0 || cl == kEnd) { kids[nk++] = c; continue; }
-                kids[nk++] = cl;
-                const int64_t cr = skip_of(cl);
-                if (cr != kEnd && cr != skip_of(c)) kids[nk++] = cr;       // right grandchild: the left one's skip link, unless that already leaves the subtree of c
-            }
-            WNode w; std::memset(&w, 0, sizeof w);
-            float* lo[3] = {&w.lox.x, &w.loy.x, &w.loz.x}; float* hi[3] = {&w.hix.x, &w.hiy.x, &w.hiz.x};
-            int refs[4] = {kWNone, kWNone, kWNone, kWNone};
-            std::vector<Job> sub;
-            for (int j = 0; j < nk; j++)
-            {
-                const NodeQ& q = nodes[(size_t)kids[j]];
-                lo[0][j] = q.lo.x; lo[1][j] = q.lo.y; lo[2][j] = q.lo.z; hi[0][j] = q.hi.x; hi[1][j] = q.hi.y; hi[2][j] = q.hi.z;
-                if (cnt_of(kids[j]) > 0) refs[j] = ~(int)kids[j];
-                else { refs[j] = (int)out.wide.size(); out.wide.emplace_back(); sub.push_back({kids[j], refs[j], jb.depth + 1}); }
-            }
-            w.ref = int4{refs[0], refs[1], refs[2], refs[3]};
-            out.wide[(size_t)jb.wide] = w;
-            for (size_t k = sub.size(); k-- > 0;) jobs.push_back(sub[k]);          // first child's subtree gets the next indices
-        }
-        return rootWide;
-    };
-    out.wide.clear();
-    if (out.ok && reachableT > 0 && HRT_ENV("HRT_WIDE") && atoi(HRT_ENV("HRT_WIDE")) > 0)        // experiment, off by default
-    {
-        int dT = 0;
-        out.wide_tlas_root = collapse(out.tlas, 0, dT);
-        int dB = 0;
-        bool fits = true;
-        for (int64_t i = 0; i < nTI; i++)
-        {
-            FInst& f = out.finst[(size_t)i];
-            if (__builtin_bit_cast(int, f.a.w) & FI_FAST_SPHERE) continue;
-            const int root = __builtin_bit_cast(int, f.c.x), end = __builtin_bit_cast(int, f.c.y);
-            int d = 0, ref = kWNone;
-            if (root < end)
-            {   // several leaf slots may share one BLAS range: collapse it once
-                bool found = false;
-                for (int64_t k = 0; k < i && !found; k++)
-                    if (!(__builtin_bit_cast(int, out.finst[(size_t)k].a.w) & FI_FAST_SPHERE) && __builtin_bit_cast(int, out.finst[(size_t)k].c.x) == root && i - k < 64)
-                    { ref = __builtin_bit_cast(int, out.finst[(size_t)k].c.w); found = true; }
-                if (!found) ref = collapse(out.blas, root, d);
-            }
-            dB = std::max(dB, d);
-            f.c.w = bits_f(ref);
-            if (out.wide.size() > (size_t)0x3FFFFFFF) fits = false;
-        }
-        out.wide_depth = dT + dB;
-        if (!fits) { out.wide.clear(); out.wide_depth = 0; }
-    }
-    if (out.wide.empty()) { out.wide.assign(1, WNode{}); out.wide_depth = 0; }
-    (void)wideDepthMax;
-
     // ---- sphere-instance scenes: instance records inlined into the TLAS node stream (hrt_walker.hpp).  A leaf is followed by
     // one record per instance holding the box of its one-node BLAS; the walker treats them as nodes (count field 15), so the
     // instance box tests ride the node steps and their lookahead instead of costing a leaf step each.
@@ -1130,6 +1141,20 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nO
         HIPCHK(c, hipMalloc(&v, (size_t)3 * (size_t)nOrd * sizeof(float)));
         d.wf_accum = (float*)v; d.wf_accum_floats = (size_t)3 * (size_t)nOrd;
     }
+    if (d.tl_ok)
+    {   // queues of the treelet walker: per walk kind key / state / binned indices over the path slots, and the per-treelet counters
+        const size_t nTl = (size_t)d.dtl.nTl;
+        const size_t ints = ((nTl + 32 + nTl + 1 + nTl) + 63) & ~(size_t)63;
+        const size_t per0 = (size_t)cap * (4 + 16 + 4) + ints * 4, per1 = (size_t)cap * (4 + 32 + 4) + ints * 4;
+        const size_t need = ((per0 + 255) & ~(size_t)255) + per1;
+        if (need > d.tlq_bytes[lane])
+        {
+            if (d.tlq_mem[lane]) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(d.tlq_mem[lane]); d.tlq_mem[lane] = nullptr; d.tlq_bytes[lane] = 0; }
+            void* v = nullptr;
+            HIPCHK(c, hipMalloc(&v, need));
+            d.tlq_mem[lane] = v; d.tlq_bytes[lane] = need;
+        }
+    }
     float* m = d.wf_mem[lane];
     auto take = [&](int nplanes, long long stride) { Planes pl; pl.base = m; pl.stride = stride; m += (size_t)nplanes * (size_t)stride; return pl; };
     W.A = take(V_PLANES, cap); W.B = take(V_PLANES, cap); W.R = take(R_PLANES, cap); W.SQ = take(S_PLANES, cap);
@@ -1137,8 +1162,51 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nO
     W.accum.base = d.wf_accum; W.accum.stride = nOrd;
     W.cntA = d.wf_cnt[lane]; W.cntS = d.wf_cnt[lane] + (size_t)(maxDepth + 1) * (size_t)nRanges;
     W.grab = d.wf_cnt[lane] + (size_t)(2 * maxDepth + 2) * (size_t)nRanges;
-    W.ovf = d.wf_ovf;
     W.nRanges = nRanges;
+    return HRT_OK;
+}
+
+
+// queues of the treelet walker for one batch lane and walk kind (0 shadow, 1 closest), carved from DeviceState::tlq_mem
+TlQueues tl_queues(const DeviceState& d, int lane, int kind, long long cap)
+{
+    const size_t nTl = (size_t)d.dtl.nTl;
+    const size_t ints = ((nTl + 32 + nTl + 1 + nTl) + 63) & ~(size_t)63;
+    const size_t per0 = (size_t)cap * (4 + 16 + 4) + ints * 4;
+    char* p = (char*)d.tlq_mem[lane] + (kind ? ((per0 + 255) & ~(size_t)255) : 0);
+    TlQueues Q;
+    Q.state = (float4*)p; p += (size_t)cap * (kind ? 32 : 16);
+    Q.key = (int*)p; p += (size_t)cap * 4;
+    Q.sorted = (int*)p; p += (size_t)cap * 4;
+    Q.hist = (int*)p; Q.misc = Q.hist + nTl; Q.offs = Q.misc + 32; Q.curs = Q.offs + nTl + 1;
+    return Q;
+}
+
+#ifndef HRT_TL_ROUNDS
+#define HRT_TL_ROUNDS 3
+#endif
+// One walk launch of the streamed pipeline through the treelet walker: fresh rays, kTlRounds rounds over the binned rays, clean-up.
+template <int F, bool ANY, bool EXISTS, int LT>
+int launch_tl_walk(hrt_ctx* c, DeviceState& d, const TracerPackedT<F>& tr, const WfBuffers& W, int lane, long long cap, int depth, hipStream_t st, dim3 gridW, dim3 gridR)
+{
+    const DTreelets& T = d.dtl;
+    const TlQueues Q = tl_queues(d, lane, ANY ? 0 : 1, cap);
+    const int histBins = T.nTl <= kTlHistLds ? T.nTl : 0;
+    const size_t lds0 = tl_shared_bytes(0, T.redLds, histBins), lds1 = tl_shared_bytes(T.tlBytesMax, T.redLds, histBins);
+    static const int rounds = HRT_ENV("HRT_TL_ROUNDS") ? std::max(0, atoi(HRT_ENV("HRT_TL_ROUNDS"))) : HRT_TL_ROUNDS;
+    if (lds1 > 65536) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&hrt_tl_walk_kernel<F, ANY, EXISTS, LT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    const dim3 block(256), grid1((unsigned)(d.n_cu * 8));
+    HIPCHK(c, hipMemsetAsync(Q.hist, 0, ((size_t)T.nTl + 32) * sizeof(int), st));
+    const int* cnt = (ANY ? W.cntS : W.cntA) + (size_t)depth * W.nRanges;
+    hipLaunchKernelGGL((hrt_tl_walk_kernel<F, ANY, EXISTS, LT, 0>), gridW, block, lds0, st, tr, T, Q, W, depth, histBins, 0, 0);
+    for (int r = 0; r < rounds; r++)
+    {
+        hipLaunchKernelGGL(hrt_tl_scan_kernel, dim3(1), dim3(1024), 0, st, Q, T.nTl);
+        hipLaunchKernelGGL(hrt_tl_scatter_kernel, gridR, block, 0, st, Q, T.nTl, cnt, W.nRanges);
+        hipLaunchKernelGGL((hrt_tl_walk_kernel<F, ANY, EXISTS, LT, 1>), grid1, block, lds1, st, tr, T, Q, W, depth, histBins, T.tlBytesMax, r + 1);
+    }
+    hipLaunchKernelGGL((hrt_tl_walk_kernel<F, ANY, EXISTS, LT, 2>), gridW, block, lds0, st, tr, T, Q, W, depth, histBins, 0, 0);
+    HIPCHK(c, hipGetLastError());
     return HRT_OK;
 }
 
@@ -1147,7 +1215,7 @@ template <int F> struct PackedFeat<TracerPackedT<F>> { static constexpr int valu
 
 template <class TR>
 int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, const TileMap& tm, int width,
-                   const DReservoir& resPrev, const DReservoir& resCur, long long nPix, bool count, bool mega)
+                   const DReservoir& resPrev, const DReservoir& resCur, long long nPix, bool count, bool mega, bool treelets = false)
 {
     unsigned long long* cnt1 = d.counters + 10;
     if (tm.nTiles <= 0) return HRT_OK;
@@ -1235,24 +1303,8 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const dim3 block(256), gridR((nRanges + 3) / 4), gridP((g.nOrd + 255) / 256);
     // walk launches are persistent: enough workgroups to fill every wave slot, each wave pulls ranges until none is left
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * (nLanes >= 2 ? kWalkBlocksPerCU2 : kWalkBlocksPerCU)));
-    // wide walker (experiment, HRT_WIDE=1 at upload and render time; production frames only): needs the collapsed trees and a
-    // stack bound that fits LDS + overflow area.  Parity-green, but not faster than the binary walker.
-    static const int wideEnv = HRT_ENV("HRT_WIDE") ? atoi(HRT_ENV("HRT_WIDE")) : 0;
     static const bool forkShadow = HRT_ENV("HRT_NO_FORK") == nullptr;       // A/B knob
     static const bool forkStatic = HRT_ENV("HRT_FORK_STATIC") != nullptr;   // A/B knob
-#ifdef HRT_TUNING
-    const bool wide = wideEnv > 0 && !count && PackedFeat<TR>::value >= 0 && c->wide_depth > 0 && c->wide_depth <= kWideMaxDepth;
-    if (wide && !d.wf_ovf)
-    {
-        void* v = nullptr;
-        HIPCHK(c, hipMalloc(&v, (size_t)kMaxLanes * 2 * (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf * sizeof(int)));      // one area per lane and walk kind
-        d.wf_ovf = (int*)v;
-    }
-    if (wide) for (int j = 0; j < kMaxLanes; j++) Wl[j].ovf = d.wf_ovf + (size_t)j * 2 * (size_t)std::max<long long>((long long)d.n_cu * kWalkBlocksPerCU, 1) * 256 * kWStackOvf;
-#else
-    constexpr bool wide = false;
-    (void)wideEnv;
-#endif
     int batch = 0;
     for (int b0 = 0; b0 < spp; b0 += (int)sb, batch++)
     {
@@ -1271,7 +1323,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
 #else
             const bool lastBounce = depth + 1 >= k.maxDepth;        // its closest-hit walk only decides hit or miss
 #endif
-            const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0 || wide) ? 1 : 0;      // the wide walker's overflow area is sized for the persistent grid
+            const int chained = (PackedFeat<TR>::value > 0 || HRT_CHAIN_FEAT0) ? 1 : 0;
             if (depth == 0)
             {
                 if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, true>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
@@ -1284,7 +1336,18 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 constexpr int F = PackedFeat<TR>::value;
                 // production walks.  Boolean queries (shadow rays, the last bounce's hit-or-miss) of fast-sphere scenes walk the
                 // device-built tree over the same instances when one was made at upload (hrt_walker.hpp, ALT)
+                // scenes with big triangle meshes: the treelet-queued walker (hrt_walker_tl.hpp)
+                const bool useTl = F != 0 && treelets && d.tl_ok && !count;
+                int tlRc = HRT_OK;
                 auto launch_shadow = [&](hipStream_t st) {
+                    if constexpr (F != 0)
+                        if (useTl)
+                        {
+                            const int rcT = d.dpacked.leafTris == 3 ? launch_tl_walk<F, true, false, 3>(c, d, tr, W, lane, cap, depth, st, gridW, gridR)
+                                                                    : launch_tl_walk<F, true, false, 2>(c, d, tr, W, lane, cap, depth, st, gridW, gridR);
+                            if (rcT != HRT_OK) tlRc = rcT;
+                            return;
+                        }
                     if constexpr (F == 0)
                         if (d.any_ok)
                         {
@@ -1309,6 +1372,17 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 const bool secondClosest = second;
 #endif
                 auto launch_closest = [&](hipStream_t st) {
+                    if constexpr (F != 0)
+                        if (useTl)
+                        {
+                            const bool lt3 = d.dpacked.leafTris == 3;
+                            const int rcT = lastBounce ? (lt3 ? launch_tl_walk<F, false, true, 3>(c, d, tr, W, lane, cap, depth, st, gridW, gridR)
+                                                              : launch_tl_walk<F, false, true, 2>(c, d, tr, W, lane, cap, depth, st, gridW, gridR))
+                                                       : (lt3 ? launch_tl_walk<F, false, false, 3>(c, d, tr, W, lane, cap, depth, st, gridW, gridR)
+                                                              : launch_tl_walk<F, false, false, 2>(c, d, tr, W, lane, cap, depth, st, gridW, gridR));
+                            if (rcT != HRT_OK) tlRc = rcT;
+                            return;
+                        }
                     if constexpr (F == 0)
                         if (lastBounce ? d.any_ok : secondClosest)
                         {
@@ -1333,14 +1407,6 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, sMain, tr, tr, W, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
                 }
-#ifdef HRT_TUNING
-                else if (wide)
-                {
-                    hipLaunchKernelGGL((hrt_wf_walkw_shadow_kernel<F>), chained ? gridW : gridR, block, 0, sMain, tr, W, vsel, depth, chained);
-                    hipLaunchKernelGGL((hrt_wf_walkw_closest_kernel<F>), chained ? gridW : gridR, block, 0, sMain, tr, W, depth, chained);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
-                }
-#endif
                 else if ((chained || forkStatic) && forkShadow)
                 {   // the two walks of a bounce are independent (shadow requests vs bounce rays) and both are persistent
                     // launches that end in a drain: on two streams the second one's workgroups move into the wave slots
@@ -1359,6 +1425,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     launch_closest(sMain);
                     hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trFin, k, W, vsel, depth);
                 }
+                if (tlRc != HRT_OK) return tlRc;
             }
             else
             {   // reference layout: one-ray-per-lane walks
@@ -1393,10 +1460,12 @@ extern "C" {
 
 const char* hrt_version(void)
 {
-#ifdef HRT_TUNING
-    return "hip_raytrace 0.3 (gfx950) tuning-build";
+#if defined(HRT_TUNING)
+    return "hip_raytrace 0.4 (gfx950) tuning-build";
+#elif defined(HRT_TEST_HOOKS)
+    return "hip_raytrace 0.4 (gfx950) test-hooks";
 #else
-    return "hip_raytrace 0.3 (gfx950)";
+    return "hip_raytrace 0.4 (gfx950)";
 #endif
 }
 
@@ -1432,6 +1501,7 @@ try {
         d.device_id = ids[i];
         hipError_t err = hipSetDevice(d.device_id);
         if (err == hipSuccess) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, d.device_id) == hipSuccess && cu > 0) d.n_cu = cu; }
+        if (err == hipSuccess) { int lds = 0; if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, d.device_id) == hipSuccess && lds > 0) d.max_lds = lds; }
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
         if (err == hipSuccess) err = hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking);
         for (int j = 1; j < kBatchLanes && err == hipSuccess; j++)
@@ -1555,7 +1625,6 @@ try {
     c->small_scene = (s->n_tlasNodes + s->n_blasNodes) <= kSmallSceneNodes;
     c->flat_leaves = ph.n_flat;
     c->own_in_world = ph.own_in_world;
-    c->wide_depth = ph.wide_depth;
     c->refit_ok = ph.refit_ok && ph.ok;
     c->feat_alpha = (ph.feat & 2) != 0;
     c->n_inst = s->n_instances; c->n_tlas = s->n_tlasNodes; c->n_slots = s->n_tlasInstanceIndices; c->n_blas = s->n_blasNodes;
@@ -1573,6 +1642,8 @@ try {
     const int64_t capTI = std::max<int64_t>(std::max<int64_t>(s->n_tlasInstanceIndices, s->n_instances), 1);
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
+    TreeletsHost tlh;
+    if (ph.ok && (ph.feat & 1) && ph.blas_refit_ok && !ph.meshRanges.empty()) build_treelets(ph.blas, ph.bsubend, ph.meshRanges, g_treelet_limits, tlh);
     for (DeviceState& d : c->dev)
     {
         HIPCHK(c, hipSetDevice(d.device_id));
@@ -1598,13 +1669,14 @@ try {
         S.texInfos = (const hrt_tex_info*)d.scene[14];
         S.n_texInfos = (int32_t)(cnt[14] > 0 ? cnt[14] : 1);
         // device-private repack (TracerPacked)
-        const void* psrc[7] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), ph.wide.data(), ph.tlasX.data()};
+        const void* psrc[7] = {ph.tlas.data(), ph.finst.data(), ph.blas.data(), ph.ftri.data(), ph.flat.data(), nullptr, ph.tlasX.data()};       // slot 5 unused
         const size_t pbytes[7] = {ph.tlas.size() * sizeof(NodeQ), ph.finst.size() * sizeof(FInst), ph.blas.size() * sizeof(NodeQ), ph.ftri.size() * sizeof(FTri),
-                                  ph.flat.size() * sizeof(NodeQ), ph.wide.size() * sizeof(WNode), ph.tlasX.size() * sizeof(NodeQ)};
+                                  ph.flat.size() * sizeof(NodeQ), 0, ph.tlasX.size() * sizeof(NodeQ)};
         const size_t proom[7] = {(size_t)capT * sizeof(NodeQ), (size_t)capTI * sizeof(FInst), 0, 0, (size_t)kFlatMaxLeaves * sizeof(NodeQ), 0,
                                  (size_t)(capT + capTI) * sizeof(NodeQ)};
         for (int i = 0; i < 7; i++)
         {
+            if (!psrc[i]) continue;
             HIPCHK(c, hipMalloc(&d.packed[i], std::max(pbytes[i], proom[i])));
             HIPCHK(c, hipMemcpyAsync(d.packed[i], psrc[i], pbytes[i], hipMemcpyHostToDevice, d.stream));
         }
@@ -1661,7 +1733,6 @@ try {
         d.dpacked.tlas = (const NodeQ*)d.packed[0]; d.dpacked.finst = (const FInst*)d.packed[1];
         d.dpacked.blas = (const NodeQ*)d.packed[2]; d.dpacked.ftri = (const FTri*)d.packed[3];
         d.dpacked.nTlas = (int)ph.tlas.size();
-        d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = ph.wide_tlas_root;
         d.dpacked.tlasX = ph.n_tlasX > 0 ? (const NodeQ*)d.packed[6] : nullptr; d.dpacked.nTlasX = ph.n_tlasX;
         {   // triangle records per leaf step of the walker: three where leaves of three outnumber the fuller ones, else two (hrt_walker.hpp)
             size_t n3 = 0, n4 = 0;
@@ -1671,6 +1742,23 @@ try {
                 if (cnt == 3) n3++; else if (cnt >= 4) n4++;
             }
             d.dpacked.leafTris = n3 > n4 ? 3 : 2;
+        }
+        // treelets of the big triangle-mesh BLASes: what the LDS-staged walker of production frames walks (hrt_walker_tl.hpp)
+        if (ph.ok && (ph.feat & 1) && ph.blas_refit_ok && !ph.meshRanges.empty() && !tlh.tl.empty())
+        {
+            const void* tsrc[3] = {tlh.red.data(), tlh.tl.data(), tlh.redOfRoot.data()};
+            const size_t tbytes[3] = {tlh.red.size() * sizeof(NodeQ), tlh.tl.size() * sizeof(Treelet), tlh.redOfRoot.size() * sizeof(int32_t)};
+            for (int i = 0; i < 3; i++)
+            {
+                HIPCHK(c, hipMalloc(&d.tlmem[i], tbytes[i]));
+                HIPCHK(c, hipMemcpyAsync(d.tlmem[i], tsrc[i], tbytes[i], hipMemcpyHostToDevice, d.stream));
+            }
+            d.dtl.red = (const NodeQ*)d.tlmem[0]; d.dtl.tl = (const Treelet*)d.tlmem[1]; d.dtl.redOfRoot = (const int*)d.tlmem[2];
+            d.dtl.nTl = (int)tlh.tl.size(); d.dtl.nRed = (int)tlh.red.size();
+            d.dtl.redLds = (int)std::min<size_t>(tlh.red.size(), (size_t)kTlRedLdsMax);
+            d.dtl.tlBytesMax = (tlh.tlBytesMax + 15) & ~15;
+            const int histBins = d.dtl.nTl <= kTlHistLds ? d.dtl.nTl : 0;
+            d.tl_ok = tl_shared_bytes(d.dtl.tlBytesMax, d.dtl.redLds, histBins) <= (size_t)d.max_lds;
         }
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
         if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once)) return rcB;
@@ -2147,7 +2235,6 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
         const bool inl = !general && !c->feat_alpha && walkOrder && (int64_t)T.nT + T.nTI < kEnd && !HRT_ENV("HRT_NO_INLINE_INSTANCES");
         d.dpacked.tlasX = inl ? (const NodeQ*)d.packed[6] : nullptr;
         d.dpacked.nTlasX = inl ? T.nT + T.nTI : 0;
-        d.dpacked.wide = (const WNode*)d.packed[5]; d.dpacked.wideTlasRoot = kWNone;
         // the second tree follows the scene (same topology, new boxes) or stands down
         if ((rc = refit_second_tree(c, d, action == HRT_REBUILD_FORCE_REBUILD, !general && !c->feat_alpha && h_flags[1] == 0)) != HRT_OK) return rc;
         if (first)
@@ -2164,7 +2251,6 @@ int apply_update(hrt_ctx* c, int policy, const char* who, const std::function<in
             c->flat_leaves = (!general && !c->feat_alpha && walkOrder && c->own_in_world && h_flags[1] == 0 && c->tlas_leaves > 0 && c->tlas_leaves <= kFlatMaxLeaves) ? c->tlas_leaves : 0;
             c->n_tlas = T.nT; c->n_slots = T.nTI;
             c->small_scene = (c->n_tlas + c->n_blas) <= kSmallSceneNodes;
-            c->wide_depth = 0;                       // the 4-wide collapse is not maintained on the device
             c->tlas_on_device = true;
             first = false;
         }
@@ -2217,6 +2303,7 @@ try {
     int blasAction = 0; float blasGrowth = 0.f;
     const int rc = apply_update(c, policy, "hrt_scene_update_positions", [&](DeviceState& d, std::vector<void*>&) -> int {
         const bool meshes = d.n_mesh_inst > 0;
+        d.tl_ok = false;                                // the reduced trees hold copies of the boxes as uploaded: walks go back to the plain walker
         auto keep_base = [&]() -> int {
             HIPCHK(c, hipMemcpyAsync(d.bl.saBase, d.bl.sa, (size_t)d.bl.nB * 4, hipMemcpyDeviceToDevice, d.stream));
             d.blas_base_valid = true;
@@ -2517,7 +2604,7 @@ try {
         DReservoir resCur = even ? d.resA : d.resB;
         hipEvent_t* ev = d.ev[d.ring_head];
         int rcs = primaryOnly ? HRT_OK : with_tracer(d, [&](auto tr) -> int {
-            return run_path_stage(c, d, tr, k, tm, p->width, resPrev, resCur, (long long)nPix, count, mega);
+            return run_path_stage(c, d, tr, k, tm, p->width, resPrev, resCur, (long long)nPix, count, mega, (flags & HRT_FLAG_TREELETS) != 0);
         });
         if (rcs != HRT_OK) return rcs;
         HIPCHK(c, hipEventRecord(ev[2], d.stream));
@@ -2710,6 +2797,7 @@ try {
 }
 catch (...) { return on_exception(c, "hrt_device_buffers"); }
 
+#ifdef HRT_TEST_HOOKS
 // test hook: evaluate hrt_math.h function `fn` on device 0 of ctx (see hrt_math_probe_kernel)
 int hrt_math_probe(hrt_ctx* c, int fn, int n, const float* x, const float* y, float* out)
 try {
@@ -2752,8 +2840,56 @@ try {
     return HRT_OK;
 }
 catch (...) { return on_exception(c, "hrt_math_exhaustive"); }
+#endif // HRT_TEST_HOOKS
 
 } // extern "C"
+
+#ifdef HRT_TEST_HOOKS
+// test hooks of the treelet cut (include/hrt_test_hooks.h)
+extern "C" int hrt_debug_set_treelet_limits(int bytes, int min_nodes, int min_blas_nodes)
+{
+    g_treelet_limits = TreeletLimits{};
+    if (bytes > 0) { g_treelet_limits.bytes = bytes; g_treelet_limits.minNodes = min_nodes; g_treelet_limits.minBlasNodes = min_blas_nodes; }
+    if (min_blas_nodes < 0) g_treelet_limits.minBlasNodes = 0x7FFFFFFF;
+    return 0;
+}
+
+extern "C" int hrt_debug_treelet_count(hrt_ctx* c)
+{
+    if (!c || c->dev.empty()) return 0;
+    return c->dev[0].tl_ok ? c->dev[0].dtl.nTl : 0;
+}
+
+extern "C" int hrt_debug_treelets(const hrt_scene_desc* s, int bytes, int min_nodes, int min_blas_nodes,
+                                  float* blas, float* red, int32_t* red_orig, int32_t* treelets, int32_t* red_of_root, int64_t* counts)
+try {
+    if (!s || !counts) return HRT_ERR_INVALID_ARG;
+    PackedHost ph;
+    if (!validate_and_pack(s, ph).empty()) return HRT_ERR_INVALID_ARG;
+    TreeletLimits lim;
+    if (bytes > 0) { lim.bytes = bytes; lim.minNodes = min_nodes; lim.minBlasNodes = min_blas_nodes; }
+    TreeletsHost th;
+    if (ph.ok && (ph.feat & 1) && ph.blas_refit_ok && !ph.meshRanges.empty()) build_treelets(ph.blas, ph.bsubend, ph.meshRanges, lim, th);
+    counts[0] = (int64_t)ph.blas.size(); counts[1] = (int64_t)th.red.size(); counts[2] = (int64_t)th.tl.size();
+    if (blas) std::memcpy(blas, ph.blas.data(), ph.blas.size() * sizeof(NodeQ));
+    if (red && !th.red.empty()) std::memcpy(red, th.red.data(), th.red.size() * sizeof(NodeQ));
+    if (red_orig && !th.redOrig.empty()) std::memcpy(red_orig, th.redOrig.data(), th.redOrig.size() * sizeof(int32_t));
+    if (treelets && !th.tl.empty()) std::memcpy(treelets, th.tl.data(), th.tl.size() * sizeof(Treelet));
+    if (red_of_root && !th.redOfRoot.empty()) std::memcpy(red_of_root, th.redOfRoot.data(), th.redOfRoot.size() * sizeof(int32_t));
+    return HRT_OK;
+}
+catch (...) { return on_exception(nullptr, "hrt_debug_treelets"); }
+#endif // HRT_TEST_HOOKS
+
+#ifdef HRT_TL_STATS
+// variant builds only (tools/tl_stats.py): read and clear the treelet walker's statistics of the current device
+extern "C" int hrt_debug_tl_stats(unsigned long long* out256)
+{
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_tl_stats), sizeof(g_tl_stats)) != hipSuccess) return -1;
+    static const unsigned long long zero[8][2][16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_stats), zero, sizeof(g_tl_stats)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef HRT_PT_STATS
 // variant builds only (tools/pt_stats.py): read and clear the fused kernel's section statistics of the current device
@@ -2767,6 +2903,7 @@ extern "C" int hrt_debug_pt_stats(unsigned long long* out64)
 }
 #endif
 
+#ifdef HRT_TEST_HOOKS
 // ---- host-only test hooks of the second tree (include/hip_raytrace.h)
 extern "C" {
 
@@ -2801,6 +2938,7 @@ try {
 catch (...) { return on_exception(nullptr, "hrt_debug_second_tree_reorder"); }
 
 } // extern "C"
+#endif // HRT_TEST_HOOKS
 
 #ifdef HRT_WALK_STATS
 // variant builds only (tools/walk_stats.py): read and clear the walker's phase statistics of the current device

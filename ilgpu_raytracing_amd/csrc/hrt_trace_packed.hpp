@@ -33,14 +33,6 @@ struct NodeQ { float4 lo, hi; };            // lo.w = bits(left | first), hi.w =
 struct FInst { float4 a, b, c; };           // a.w = bits(flags), b.w = bits(index); see hrt_runtime.hip pack_scene()
 struct FTri  { float4 v0, v1, v2; };        // v0.w = bits(triIndex), v1.w = bits(matIndex), v2.w = bits(flags)
 
-// WNode 128 B (one cache line): the binary tree collapsed two levels at a time.  Up to 4 children in WALK ORDER with their
-// exact boxes, child-major per coordinate (lox = lo.x of children 0..3, ...).  ref[j] >= 0: index of the child's WNode;
-// ref[j] < 0 and != kWNone: ~ref[j] is the index of the child's LEAF record in the binary NodeQ array (first, count and the box
-// again); kWNone: no child.  Inner nodes only accelerate, so how they are grouped is free as long as leaves are
-// met in walk order and take their own exact test at entry.
-struct WNode { float4 lox, loy, loz, hix, hiy, hiz; int4 ref; int4 pad; };
-constexpr int kWNone = (int)0x80000000;
-
 enum { FI_FAST_SPHERE = 1, FI_IDENTITY = 2, FI_SPHERESET = 4 };
 enum { FT_TEXTURED = 1, FT_TWOSIDED = 2 };  // FT_TEXTURED: usable diffuse or alpha map, or AlphaCutoff > 1 (rejects alpha = 1)
 
@@ -64,8 +56,6 @@ struct DPacked {
     int nTlas;               // records in tlas (>= 1)
     const NodeQ* tlasX;      // sphere-instance scenes (FEAT 0): the TLAS with every leaf followed by one record per instance
     int nTlasX;              //   (box of the instance's one-node BLAS, count field 15, link = leaf slot, skip = next record): nullptr if not built
-    const WNode* wide;       // 4-wide collapse of the TLAS and of every BLAS (nullptr: not built for this scene)
-    int wideTlasRoot;        // reference (WNode index or ~leaf) of the TLAS root; every general FInst carries its BLAS root in c.w
     int leafTris;            // triangle records the walker fetches per leaf step (2 or 3: hrt_walker.hpp)
     const int* slotMap;      // second tree over the same instances (hrt_walker.hpp, ALT): leaf slot of the uploaded tree -> leaf slot here; else nullptr
     const NodeQ* tlasXO;     // second tree only: tlasX two or four times over, one numbering per combination of the signs of a ray's direction along

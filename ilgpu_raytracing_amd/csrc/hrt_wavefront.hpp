@@ -34,9 +34,6 @@
 #pragma once
 #include "hrt_device.hpp"
 #include "hrt_walker.hpp"
-#ifdef HRT_TUNING
-#include "hrt_walker_wide.hpp"          // experimental 4-wide walker: measured slower, tuning builds only
-#endif
 
 namespace hrt {
 
@@ -82,7 +79,6 @@ struct WfBuffers {
     int* cntA;                   // [depth][range] live paths of a range at a depth
     int* cntS;                   // [depth][range] shadow requests
     int* grab;                   // [depth][2][8] range hand-out counters of the walk launches (zeroed per sample batch)
-    int* ovf;                    // wide walker: stack levels beyond kWStackLds, kWStackOvf ints per resident lane
     int nRanges;
 };
 
@@ -468,44 +464,6 @@ HRT_D void wf_walk_closest_wave(const TracerPackedT<FEAT>& tr, const TracerPacke
             W.R.st4(RQ_H, slot, mkq(res.t, res.tObj, __int_as_float(res.slot), __int_as_float(res.prim)));
         }, C);
 }
-
-#ifdef HRT_TUNING
-// the same two walks over the 4-wide collapse (hrt_walker_wide.hpp); production frames only (no work counters)
-template <int FEAT>
-HRT_D void wf_walkw_shadow_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, const Planes& V, int depth, int* grabCtr, int ownRange)
-{
-    RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
-    const int* cnt = W.cntS + (size_t)depth * W.nRanges;
-    walk_queue_wide<FEAT, true>(tr, W.ovf,
-        [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
-        [&](int q, Ray& r, float& tMax) {
-            const float4 qa = W.SQ.ld4(SQ_A, q), qb = W.SQ.ld4(SQ_B, q);
-            r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d); tMax = 1e29f; return true;
-        },
-        [&](int q, const WalkResult& res) {
-            if (!res.occluded) W.SQ.sti(S_VIS, q, 1);         // wf_finish_wave adds the request's light to its vertex
-        });
-}
-
-template <int FEAT>
-HRT_D void wf_walkw_closest_wave(const TracerPackedT<FEAT>& tr, const WfBuffers& W, int depth, int* grabCtr, int ownRange)
-{
-    RangeGrab G; G.init(grabCtr, W.nRanges, ownRange);
-    const int* cnt = W.cntA + (size_t)depth * W.nRanges;
-    walk_queue_wide<FEAT, false>(tr, W.ovf,
-        [&](int& base, int& n) { for (;;) { const int r = G.next(); if (r < 0) return false; n = cnt[r]; base = r * kRange; if (n > 0) return true; } },
-        [&](int slot, Ray& r, float& tMax) {
-            tMax = 1e30f;
-            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
-            if (__float_as_int(qb.z) & RF_DEAD) return false;
-            r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
-            return true;
-        },
-        [&](int slot, const WalkResult& res) {
-            W.R.st4(RQ_H, slot, mkq(res.t, res.tObj, __int_as_float(res.slot), __int_as_float(res.prim)));
-        });
-}
-#endif
 
 // next vertex or end of path from the raw winners (TraceNext :659-671, :241-243), with segmented compaction
 // The four waves of a workgroup own four consecutive ranges.  Their survivors are packed TOGETHER into the front of that

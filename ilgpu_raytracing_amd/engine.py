@@ -26,6 +26,8 @@ from . import _types as T
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HRT_LIB") or os.path.join(_HERE, "csrc", "libhip_raytrace.so")   # HRT_LIB: A/B builds of the same library
 _LIB = None
+_HOOKS = None
+HOOKS_LIB_PATH = os.environ.get("HRT_HOOKS_LIB") or os.path.join(_HERE, "csrc", "libhip_raytrace_test.so")
 
 
 class HrtError(RuntimeError):
@@ -36,73 +38,90 @@ class HrtError(RuntimeError):
         self.code = code
 
 
-def lib():
-    """Loads libhip_raytrace.so (built by `python -c 'import __graft_entry__ as g; g.build()'`)."""
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libhip_raytrace.so is not built (%s). Run __graft_entry__.build(); "
-                              "there is no CPU fallback for the render path." % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        L.hrt_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
-        L.hrt_destroy.argtypes = [C.c_void_p]
-        L.hrt_destroy.restype = None
-        L.hrt_last_error.argtypes = [C.c_void_p]
-        L.hrt_last_error.restype = C.c_char_p
-        L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
-        L.hrt_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
-        L.hrt_scene_update_positions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
-        L.hrt_scene_update_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
-        L.hrt_scene_download_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
-        L.hrt_scene_download_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                              C.POINTER(C.c_int64)]
-        L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
-        L.hrt_synchronize.argtypes = [C.c_void_p, C.POINTER(T.Stats)]
-        L.hrt_present.argtypes = [C.c_void_p, C.POINTER(T.PresentParams), C.c_void_p]
-        L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
-        L.hrt_reset_history.argtypes = [C.c_void_p]
-        L.hrt_frame_times.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
-        L.hrt_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-        L.hrt_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
-        L.hrt_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
+def _load(path, hooks=False):
+    if not os.path.exists(path):
+        raise ImportError("%s is not built. Run __graft_entry__.build(); there is no CPU fallback for the render path." % path)
+    L = C.CDLL(path)
+    L.hrt_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.hrt_destroy.argtypes = [C.c_void_p]
+    L.hrt_destroy.restype = None
+    L.hrt_last_error.argtypes = [C.c_void_p]
+    L.hrt_last_error.restype = C.c_char_p
+    L.hrt_scene_upload.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+    L.hrt_scene_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+    L.hrt_scene_update_positions.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+    L.hrt_scene_update_spheres.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(T.BvhUpdateStats)]
+    L.hrt_scene_download_array.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.hrt_scene_download_tlas.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                          C.POINTER(C.c_int64)]
+    L.hrt_render_frame.argtypes = [C.c_void_p, C.POINTER(T.FrameParams), C.POINTER(T.RenderOpts), C.POINTER(T.Outputs), C.POINTER(T.Stats)]
+    L.hrt_synchronize.argtypes = [C.c_void_p, C.POINTER(T.Stats)]
+    L.hrt_present.argtypes = [C.c_void_p, C.POINTER(T.PresentParams), C.c_void_p]
+    L.hrt_device_buffers.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.DeviceViews)]
+    L.hrt_reset_history.argtypes = [C.c_void_p]
+    L.hrt_frame_times.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.hrt_host_register.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.hrt_host_unregister.argtypes = [C.c_void_p, C.c_void_p]
+    L.hrt_set_workspace_limit.argtypes = [C.c_void_p, C.c_int64]
+    L.hrt_device_count.restype = C.c_int
+    L.hrt_version.restype = C.c_char_p
+    L.hrth_scene_new.restype = C.c_void_p
+    L.hrth_scene_free.argtypes = [C.c_void_p]
+    L.hrth_scene_free.restype = None
+    L.hrth_scene_clear.argtypes = [C.c_void_p]
+    L.hrth_scene_build_default.argtypes = [C.c_void_p]
+    L.hrth_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.hrth_scene_add_sphere.argtypes = [C.c_void_p, C.POINTER(T.Sphere)]
+    L.hrth_scene_build_sphere_instance.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(T.Affine3x4)]
+    L.hrth_scene_load_mesh_instance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
+    L.hrth_mesh_load_obj.argtypes = [C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_void_p)]
+    L.hrth_mesh_get.argtypes = [C.c_void_p, C.POINTER(T.MeshDesc)]
+    L.hrth_mesh_free.argtypes = [C.c_void_p]
+    L.hrth_mesh_free.restype = None
+    L.hrth_mesh_material_name.argtypes = [C.c_void_p, C.c_int]
+    L.hrth_mesh_material_name.restype = C.c_char_p
+    L.hrth_mesh_texture_path.argtypes = [C.c_void_p, C.c_int]
+    L.hrth_mesh_texture_path.restype = C.c_char_p
+    L.hrth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]
+    L.hrth_image_free.argtypes = [C.POINTER(C.c_uint8)]
+    L.hrth_image_free.restype = None
+    L.hrth_scene_load_obj_instance.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(T.Affine3x4), C.c_float]
+    L.hrth_last_error.restype = C.c_char_p
+    L.hrth_scene_rebuild_tlas.argtypes = [C.c_void_p]
+    L.hrth_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
+    L.hrth_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+    L.hrth_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
+    L.hrth_camera_lookat.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
+    L.hrth_camera_translate.argtypes = [C.POINTER(T.Camera), C.POINTER(C.c_float)]
+    L.hrth_camera_bake.argtypes = [C.POINTER(T.Camera), C.c_int, C.c_int]
+    L.hrth_sun_dir.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+    if hooks:       # include/hrt_test_hooks.h: only in libhip_raytrace_test.so
         L.hrt_math_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.hrt_math_exhaustive.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
-        L.hrt_device_count.restype = C.c_int
-        L.hrt_version.restype = C.c_char_p
-        L.hrth_scene_new.restype = C.c_void_p
-        L.hrth_scene_free.argtypes = [C.c_void_p]
-        L.hrth_scene_free.restype = None
-        L.hrth_scene_clear.argtypes = [C.c_void_p]
-        L.hrth_scene_build_default.argtypes = [C.c_void_p]
-        L.hrth_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.hrth_scene_add_sphere.argtypes = [C.c_void_p, C.POINTER(T.Sphere)]
-        L.hrth_scene_build_sphere_instance.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(T.Affine3x4)]
-        L.hrth_scene_load_mesh_instance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                                    C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
-        L.hrth_mesh_load_obj.argtypes = [C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_void_p)]
-        L.hrth_mesh_get.argtypes = [C.c_void_p, C.POINTER(T.MeshDesc)]
-        L.hrth_mesh_free.argtypes = [C.c_void_p]
-        L.hrth_mesh_free.restype = None
-        L.hrth_mesh_material_name.argtypes = [C.c_void_p, C.c_int]
-        L.hrth_mesh_material_name.restype = C.c_char_p
-        L.hrth_mesh_texture_path.argtypes = [C.c_void_p, C.c_int]
-        L.hrth_mesh_texture_path.restype = C.c_char_p
-        L.hrth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_uint8))]
-        L.hrth_image_free.argtypes = [C.POINTER(C.c_uint8)]
-        L.hrth_image_free.restype = None
-        L.hrth_scene_load_obj_instance.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(T.Affine3x4), C.c_float]
-        L.hrth_last_error.restype = C.c_char_p
-        L.hrth_scene_rebuild_tlas.argtypes = [C.c_void_p]
-        L.hrth_scene_set_instance_transform.argtypes = [C.c_void_p, C.c_int, C.POINTER(T.Affine3x4)]
-        L.hrth_scene_get_desc.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
-        L.hrth_camera_create.argtypes = [C.c_int, C.c_int, C.c_float, C.POINTER(T.Camera)]
-        L.hrth_camera_lookat.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
-        L.hrth_camera_translate.argtypes = [C.POINTER(T.Camera), C.POINTER(C.c_float)]
-        L.hrth_camera_bake.argtypes = [C.POINTER(T.Camera), C.c_int, C.c_int]
-        L.hrth_sun_dir.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
-        _LIB = L
+        L.hrt_debug_set_treelet_limits.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.hrt_debug_treelet_count.argtypes = [C.c_void_p]
+        L.hrt_debug_treelets.argtypes = [C.POINTER(T.SceneDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_int64)]
+    return L
+
+
+def lib():
+    """Loads libhip_raytrace.so, the shipped library (built by `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _load(LIB_PATH)
     return _LIB
+
+
+def hooks():
+    """Loads libhip_raytrace_test.so: the same sources compiled with -DHRT_TEST_HOOKS (include/hrt_test_hooks.h).  Test suite only;
+    a renderer that needs a hook is created with RTRenderer(..., library=hooks())."""
+    global _HOOKS
+    if _HOOKS is None:
+        _HOOKS = _load(HOOKS_LIB_PATH, hooks=True)
+    return _HOOKS
 
 
 def _fv(v):
@@ -312,8 +331,8 @@ class RTRenderer:
     """Frame orchestration of RTRenderer.RenderDirectToPbo up to the end-of-frame Synchronize
     (RTRenderer.cs:105-205,233).  Presentation (PBO map, TAAU/blit) is out of scope."""
 
-    def __init__(self, device_ids=None, width=1280, height=720, build_default_scene=False):
-        L = lib()
+    def __init__(self, device_ids=None, width=1280, height=720, build_default_scene=False, library=None):
+        L = self._L = library or lib()
         ids = list(device_ids) if device_ids is not None else [0]
         arr = (C.c_int * len(ids))(*ids)
         h = C.c_void_p()
@@ -347,14 +366,14 @@ class RTRenderer:
 
     def close(self):
         if getattr(self, "_ctx", None):
-            lib().hrt_destroy(self._ctx)
+            self._L.hrt_destroy(self._ctx)
             self._ctx = None
 
     __del__ = close
 
     def _check(self, rc):
         if rc != 0:
-            raise HrtError(rc, (lib().hrt_last_error(self._ctx) or b"").decode())
+            raise HrtError(rc, (self._L.hrt_last_error(self._ctx) or b"").decode())
 
     def commit(self, scene_or_desc):
         """SceneManager.Commit -> BvhManager.BuildOrRefit -> Scene.UploadAll."""
@@ -363,7 +382,7 @@ class RTRenderer:
         else:
             self.scene = scene_or_desc
             d = scene_or_desc.desc()
-        self._check(lib().hrt_scene_upload(self._ctx, C.byref(d)))
+        self._check(self._L.hrt_scene_upload(self._ctx, C.byref(d)))
 
     def update_instances(self, ids, transforms, policy=T.REBUILD_AUTO):
         """BvhManager.BuildOrRefit(scene, policy) for moved instances, on the device (hrt_scene_update_instances).
@@ -376,7 +395,7 @@ class RTRenderer:
         if xf.shape[0] != ids.size:
             raise ValueError("one transform per instance id")
         st = T.BvhUpdateStats()
-        self._check(lib().hrt_scene_update_instances(self._ctx, ids.ctypes.data if ids.size else None, ids.size,
+        self._check(self._L.hrt_scene_update_instances(self._ctx, ids.ctypes.data if ids.size else None, ids.size,
                                                      xf.ctypes.data if ids.size else None, policy, C.byref(st)))
         return st
 
@@ -385,7 +404,7 @@ class RTRenderer:
         BLAS is refitted on the device, then the TLAS per `policy` (hrt_scene_update_positions).  Returns BvhUpdateStats."""
         pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
         st = T.BvhUpdateStats()
-        self._check(lib().hrt_scene_update_positions(self._ctx, int(first_vertex), pos.shape[0], pos.ctypes.data if pos.size else None,
+        self._check(self._L.hrt_scene_update_positions(self._ctx, int(first_vertex), pos.shape[0], pos.ctypes.data if pos.size else None,
                                                      policy, C.byref(st)))
         return st
 
@@ -399,7 +418,7 @@ class RTRenderer:
             buf = (T.Sphere * max(1, len(spheres)))(*spheres)
             n, ptr = len(spheres), C.addressof(buf)
         st = T.BvhUpdateStats()
-        self._check(lib().hrt_scene_update_spheres(self._ctx, int(first_sphere), n, ptr if n else None, policy, C.byref(st)))
+        self._check(self._L.hrt_scene_update_spheres(self._ctx, int(first_sphere), n, ptr if n else None, policy, C.byref(st)))
         return st
 
     def download_array(self, name, slot=0):
@@ -407,19 +426,19 @@ class RTRenderer:
         names = [n for n, _ in T.SCENE_ARRAYS]
         k = names.index(name)
         cnt = C.c_int64()
-        self._check(lib().hrt_scene_download_array(self._ctx, slot, k, None, 0, C.byref(cnt)))
+        self._check(self._L.hrt_scene_download_array(self._ctx, slot, k, None, 0, C.byref(cnt)))
         out = np.zeros(max(1, cnt.value), dtype=T.np_dtype(T.SCENE_ARRAYS[k][1]))
-        self._check(lib().hrt_scene_download_array(self._ctx, slot, k, out.ctypes.data, len(out), C.byref(cnt)))
+        self._check(self._L.hrt_scene_download_array(self._ctx, slot, k, out.ctypes.data, len(out), C.byref(cnt)))
         return out[:cnt.value]
 
     def download_tlas(self, slot=0):
         """(tlasNodes, tlasInstanceIndices, instances) of the TLAS in use, as ctypes arrays in the reference's layout."""
         cnt = (C.c_int64 * 3)()
-        self._check(lib().hrt_scene_download_tlas(self._ctx, slot, None, 0, None, 0, None, 0, cnt))
+        self._check(self._L.hrt_scene_download_tlas(self._ctx, slot, None, 0, None, 0, None, 0, cnt))
         nodes = (T.BvhNode * max(1, cnt[0]))()
         idx = (C.c_int32 * max(1, cnt[1]))()
         inst = (T.InstanceRecord * max(1, cnt[2]))()
-        self._check(lib().hrt_scene_download_tlas(self._ctx, slot, nodes, cnt[0], idx, cnt[1], inst, cnt[2], cnt))
+        self._check(self._L.hrt_scene_download_tlas(self._ctx, slot, nodes, cnt[0], idx, cnt[1], inst, cnt[2], cnt))
         return nodes, idx, inst, tuple(cnt)
 
     def set_sun_params(self, speed_rad_per_sec, elevation_rad):
@@ -463,7 +482,7 @@ class RTRenderer:
         st = T.Stats()
         opts = T.RenderOpts(flags, rows[0] if rows else 0, rows[1] if rows else 0,
                             strips[0] if strips else 1, strips[1] if strips else 0)
-        self._check(lib().hrt_render_frame(self._ctx, C.byref(params), C.byref(opts),
+        self._check(self._L.hrt_render_frame(self._ctx, C.byref(params), C.byref(opts),
                                            C.byref(outputs) if outputs is not None else None, C.byref(st)))
         self.last_params = params
         return st
@@ -478,29 +497,29 @@ class RTRenderer:
     def synchronize(self):
         """Waits for frames enqueued with FLAG_NO_SYNC; Stats.kernel_ms are sums over Stats.frames frames."""
         st = T.Stats()
-        self._check(lib().hrt_synchronize(self._ctx, C.byref(st)))
+        self._check(self._L.hrt_synchronize(self._ctx, C.byref(st)))
         return st
 
     def frame_times(self, launch=1, slot=0):
         """Per-frame HIP-event times (ms) of the frames the last synchronize() / blocking frame collected."""
         n = C.c_int(0)
-        self._check(lib().hrt_frame_times(self._ctx, slot, launch, None, 0, C.byref(n)))
+        self._check(self._L.hrt_frame_times(self._ctx, slot, launch, None, 0, C.byref(n)))
         out = np.zeros(max(1, n.value), np.float32)
-        self._check(lib().hrt_frame_times(self._ctx, slot, launch, out.ctypes.data, n.value, None))
+        self._check(self._L.hrt_frame_times(self._ctx, slot, launch, out.ctypes.data, n.value, None))
         return out[:n.value]
 
     def register_host(self, arrays):
         """Page-locks host arrays used as gather targets (hrt_host_register); arrays: dict or iterable of numpy arrays."""
         for a in (arrays.values() if isinstance(arrays, dict) else arrays):
-            self._check(lib().hrt_host_register(self._ctx, a.ctypes.data, a.nbytes))
+            self._check(self._L.hrt_host_register(self._ctx, a.ctypes.data, a.nbytes))
 
     def unregister_host(self, arrays):
         for a in (arrays.values() if isinstance(arrays, dict) else arrays):
-            self._check(lib().hrt_host_unregister(self._ctx, a.ctypes.data))
+            self._check(self._L.hrt_host_unregister(self._ctx, a.ctypes.data))
 
     def set_workspace_limit(self, max_resident_paths):
         """Caps the streamed pipeline's path workspace (0 = default): larger frames run in sample batches, same results."""
-        self._check(lib().hrt_set_workspace_limit(self._ctx, int(max_resident_paths)))
+        self._check(self._L.hrt_set_workspace_limit(self._ctx, int(max_resident_paths)))
 
     def present(self, out_width, out_height, taau=True, out=None, feedback=0.0, sharpness=0.0, clamp_k=0.0):
         """Presentation step of RenderDirectToPbo (RTRenderer.cs:208-231): TAAU resolve, or blit / bilinear upsample.
@@ -508,7 +527,7 @@ class RTRenderer:
         pp = T.PresentParams(out_width, out_height, T.PRESENT_TAAU if taau else T.PRESENT_RESAMPLE, feedback, sharpness, clamp_k)
         if out is None:
             out = np.zeros(out_width * out_height, np.int32)
-        self._check(lib().hrt_present(self._ctx, C.byref(pp), out.ctypes.data))
+        self._check(self._L.hrt_present(self._ctx, C.byref(pp), out.ctypes.data))
         return out
 
     def render_direct(self, out_width, out_height, frame, dt=0.0, render_scale=0.67, taau=True, flags=0):
@@ -520,24 +539,24 @@ class RTRenderer:
         return self.present(out_width, out_height, taau), st
 
     def reset_history(self):
-        self._check(lib().hrt_reset_history(self._ctx))
+        self._check(self._L.hrt_reset_history(self._ctx))
 
     def device_views(self, slot=0):
         v = T.DeviceViews()
-        self._check(lib().hrt_device_buffers(self._ctx, slot, C.byref(v)))
+        self._check(self._L.hrt_device_buffers(self._ctx, slot, C.byref(v)))
         return v
 
     def math_exhaustive(self, which):
         """(mismatches, bits of the first one) of a trimmed device function against its IEEE definition over its whole domain."""
         n, first = C.c_uint64(0), C.c_uint32(0)
-        self._check(lib().hrt_math_exhaustive(self._ctx, which, C.byref(n), C.byref(first)))
+        self._check(self._L.hrt_math_exhaustive(self._ctx, which, C.byref(n), C.byref(first)))
         return n.value, first.value
 
     def math_probe(self, fn, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)
         yy = np.ascontiguousarray(y, dtype=np.float32) if y is not None else None
-        self._check(lib().hrt_math_probe(self._ctx, fn, x.size, x.ctypes.data, yy.ctypes.data if yy is not None else None, out.ctypes.data))
+        self._check(self._L.hrt_math_probe(self._ctx, fn, x.size, x.ctypes.data, yy.ctypes.data if yy is not None else None, out.ctypes.data))
         return out
 
 

@@ -95,7 +95,11 @@ enum hrt_render_flags {
      * through the device pointers of hrt_device_buffers.  EXCHANGED is the caller's statement that both all-gathers of
      * the protocol are done; without it a reuse frame on a partial tile is refused (HRT_ERR_INVALID_STATE).        */
     HRT_FLAG_PRIMARY_ONLY = 1u << 6,
-    HRT_FLAG_EXCHANGED    = 1u << 7
+    HRT_FLAG_EXCHANGED    = 1u << 7,
+    HRT_FLAG_TREELETS     = 1u << 8   /* streamed production frames of scenes with big triangle meshes (>= 4096 BLAS nodes): walk them with the
+                                         LDS-staged, treelet-queued walker (csrc/hrt_walker_tl.hpp) instead of the persistent-wave walker.
+                                         Identical results; measured SLOWER on every BASELINE config (profiles/r03_treelet_walker.md),
+                                         hence opt-in.  Ignored where no treelets exist (sphere scenes, small meshes, after a vertex update).  */
 };
 
 /* Host destinations of one frame; any pointer may be NULL (not copied).  Arrays hold
@@ -283,30 +287,8 @@ int  hrt_set_workspace_limit(hrt_ctx* ctx, int64_t max_resident_paths);
 int  hrt_device_buffers(hrt_ctx* ctx, int dev, hrt_device_views* out);
 int  hrt_reset_history(hrt_ctx* ctx);           /* zero both reservoir sets */
 
-/* test hook: evaluates function `fn` of include/hrt_math.h on device slot 0 for n inputs
- * (fn ids as in tests/test_math_gpu.py); lets the GPU tests check bit-equality of the
- * arithmetic contract against the oracle.  Not needed by a production host. */
-int  hrt_math_probe(hrt_ctx* ctx, int fn, int n, const float* x, const float* y, float* out);
-
-/* test hook: compares a trimmed device-side function with its IEEE definition for EVERY float of its stated domain, on the
- * device (which: 0 = 1/sqrt(x) of Normalize for x in [1e-20, +inf], 1 = the square root of the hemisphere sampler for +0 and
- * [2^-96, +inf]).  *mismatches = number of differing results (0 expected), *first_bad (may be NULL) = bits of the smallest one. */
-int  hrt_math_exhaustive(hrt_ctx* ctx, int which, uint64_t* mismatches, uint32_t* first_bad);
-
-/* test hooks, host code only (no device, no context): what hrt_scene_upload computes on the host for the SECOND tree of a scene of
- * many one-sphere instances.
- * hrt_debug_second_tree_topology: the binned-SAH topology over the world bounds of n instances, in walk order.  order[n]: instance
- *   of every leaf slot; per node i < *n_nodes (arrays of capacity 2 n): link[i] = first slot of a leaf / index of the first child,
- *   skip[i] = next node when node i is missed (0x0FFFFFFF: none), count[i] = instances of a leaf (0: inner node), parent[i].
- * hrt_debug_second_tree_reorder: the renumbering of a node array (records of 8 floats: lo.xyz, link word, hi.xyz, skip word with
- *   the count in its top four bits; inlined != 0: every leaf is followed by one record per instance, count field 15) for rays
- *   whose direction has the signs sign[3] (+1 / -1 / 0: builder's order along that axis); links of the result are offset by base;
- *   from[i] = record of the input at position i.  Returns 0, or HRT_ERR_INVALID_ARG if the input is not such a tree. */
-int  hrt_debug_second_tree_topology(const hrt_instance* instances, int32_t n, int32_t* order, int32_t* link, int32_t* skip,
-                                    int32_t* count, int32_t* parent, int32_t* n_nodes);
-int  hrt_debug_second_tree_reorder(const float* records, int32_t n_records, const int32_t* sign, int32_t base, int32_t inlined,
-                                   float* out_records, int32_t* from);
-
+/* Test hooks (math probes, host-side builders of derived trees) are declared in hrt_test_hooks.h and exist only in
+ * libhip_raytrace_test.so, the -DHRT_TEST_HOOKS build of the same sources; the shipped library exports none of them. */
 int  hrt_device_count(void);                    /* visible HIP devices, <0 on error */
 const char* hrt_version(void);
 

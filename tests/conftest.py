@@ -32,6 +32,22 @@ def hrt_lib():
 
 
 @pytest.fixture(scope="session")
+def hooks_lib(hrt_lib):
+    """libhip_raytrace_test.so: the same sources with the test hooks of include/hrt_test_hooks.h compiled in."""
+    from ilgpu_raytracing_amd import engine
+    return engine.hooks()
+
+
+@pytest.fixture(scope="session")
+def hooks_renderer(hooks_lib):
+    """An RTRenderer on the hooks build (math probes, treelet limits); product behaviour is tested on `renderer`."""
+    from ilgpu_raytracing_amd import engine
+    r = engine.RTRenderer([0], library=hooks_lib)
+    yield r
+    r.close()
+
+
+@pytest.fixture(scope="session")
 def renderer(hrt_lib):
     """One RTRenderer (one hrt_ctx on device 0) shared by the GPU tests."""
     from ilgpu_raytracing_amd import engine

@@ -27,6 +27,21 @@ def test_exports_every_declared_symbol(hrt_lib):
     assert not missing, "libhip_raytrace.so does not export: %s" % missing
 
 
+def test_test_hooks_live_only_in_the_test_build(hrt_lib, hooks_lib):
+    """include/hrt_test_hooks.h: every hook is exported by libhip_raytrace_test.so and by nothing a production host links against."""
+    hooks = [n for n in _declared_functions("hrt_test_hooks.h") if n not in _declared_functions("hip_raytrace.h")]
+    assert "hrt_math_probe" in hooks and "hrt_debug_treelets" in hooks and len(hooks) >= 7
+    assert not [n for n in hooks if not hasattr(hooks_lib, n)], "libhip_raytrace_test.so misses a declared hook"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", engine.LIB_PATH]).decode()
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert not [n for n in hooks if n in exported], "the shipped library exports test hooks"
+    assert not [n for n in exported if "debug" in n and n.startswith("hrt")]
+    assert b"test-hooks" in hooks_lib.hrt_version() and b"test-hooks" not in hrt_lib.hrt_version()
+    # the product ABI is the same in both
+    names = _declared_functions("hip_raytrace.h") + _declared_functions("hrt_host.h")
+    assert not [n for n in names if not hasattr(hooks_lib, n)]
+
+
 def test_struct_sizes_match_headers():
     """Compile a C program against include/ and compare sizeof() with the ctypes mirrors."""
     prog = r'''

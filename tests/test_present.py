@@ -85,7 +85,7 @@ def test_second_restatement_of_the_presentation_kernels(orc, in_size, out_size, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["log", "exp", "pow"])
-def test_pow_family_bit_exact_on_gpu(orc, renderer, name):
+def test_pow_family_bit_exact_on_gpu(orc, hooks_renderer, name):
     rng = np.random.default_rng(21)
     if name == "log":
         x = np.concatenate([rng.uniform(1e-6, 4.0, 200000), [1.0, 0.5, 1e-40, 3.4e38]]).astype(np.float32); y = None
@@ -95,7 +95,7 @@ def test_pow_family_bit_exact_on_gpu(orc, renderer, name):
         x = np.concatenate([rng.uniform(0, 1.2, 200000), [0.0, 1.0]]).astype(np.float32)
         y = np.where(rng.random(x.size) < 0.5, np.float32(2.4), np.float32(1.0 / 2.4)).astype(np.float32)
     a = orc.math_eval(name, x, y)
-    b = renderer.math_probe(orc.MATH_FN[name], x, y)
+    b = hooks_renderer.math_probe(orc.MATH_FN[name], x, y)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 

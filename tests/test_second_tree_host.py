@@ -71,9 +71,9 @@ def _check_topology(n, order, link, skip, count, parent):
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_topology_is_a_walk_order_binary_tree(hrt_lib, name):
+def test_topology_is_a_walk_order_binary_tree(hooks_lib, name):
     inst = _instances(CASES[name])
-    order, link, skip, count, parent = _topology(hrt_lib, inst)
+    order, link, skip, count, parent = _topology(hooks_lib, inst)
     _check_topology(len(inst), order, link, skip, count, parent)
 
 
@@ -118,14 +118,14 @@ def _reorder(lib, X, sign, base, inlined):
 
 
 @pytest.mark.parametrize("name", ["300", "twins"])
-def test_renumberings_are_the_same_tree_near_child_first(hrt_lib, name):
+def test_renumberings_are_the_same_tree_near_child_first(hooks_lib, name):
     inst = _instances(CASES[name])
-    order, link, skip, count, parent = _topology(hrt_lib, inst)
+    order, link, skip, count, parent = _topology(hooks_lib, inst)
     X = _inlined(inst, order, link, skip, count)
     nX = len(X)
     for sign in [(1, 0, 1), (-1, 0, 1), (1, 0, -1), (-1, 0, -1), (1, 1, 1), (-1, -1, -1), (0, 0, 0)]:
         base = 1000
-        rc, out, frm = _reorder(hrt_lib, X, sign, base, True)
+        rc, out, frm = _reorder(hooks_lib, X, sign, base, True)
         assert rc == 0
         assert sorted(frm.tolist()) == list(range(nX)), "a permutation of the records"
         W, Wo = X.view(np.int32), out.view(np.int32)
@@ -154,16 +154,16 @@ def test_renumberings_are_the_same_tree_near_child_first(hrt_lib, name):
         assert seen == nX
         assert (int(Wo[0, 7]) & K_END) == K_END
     # sign (0, 0, 0) is the identity
-    rc, out, frm = _reorder(hrt_lib, X, (0, 0, 0), 0, True)
+    rc, out, frm = _reorder(hooks_lib, X, (0, 0, 0), 0, True)
     assert rc == 0 and np.array_equal(frm, np.arange(nX)) and out.tobytes() == X.tobytes()
 
 
-def test_reorder_rejects_what_is_not_such_a_tree(hrt_lib):
+def test_reorder_rejects_what_is_not_such_a_tree(hooks_lib):
     inst = _instances(CASES["300"])
-    order, link, skip, count, parent = _topology(hrt_lib, inst)
+    order, link, skip, count, parent = _topology(hooks_lib, inst)
     X = _inlined(inst, order, link, skip, count)
     bad = X.copy(); bad.view(np.int32)[0, 3] = 5                     # the root's first child is not the next record
-    assert _reorder(hrt_lib, bad, (1, 0, 1), 0, True)[0] == ERR_INVALID_ARG
+    assert _reorder(hooks_lib, bad, (1, 0, 1), 0, True)[0] == ERR_INVALID_ARG
     bad = X.copy(); bad.view(np.int32)[1, 7] = 3                     # a skip link that points backwards
-    assert _reorder(hrt_lib, bad, (1, 0, 1), 0, True)[0] == ERR_INVALID_ARG
-    assert _reorder(hrt_lib, X, (1, 0, 1), 0, False)[0] == ERR_INVALID_ARG      # inlined records where the plain layout has none
+    assert _reorder(hooks_lib, bad, (1, 0, 1), 0, True)[0] == ERR_INVALID_ARG
+    assert _reorder(hooks_lib, X, (1, 0, 1), 0, False)[0] == ERR_INVALID_ARG      # inlined records where the plain layout has none
