@@ -302,6 +302,8 @@ Image load_bmp(const std::string& file)
 struct Inflater {
     const uint8_t* in; size_t n, pos = 0; uint32_t bitbuf = 0; int bitcnt = 0; const std::string& file;
     std::vector<uint8_t> out;
+    size_t limit = (size_t)-1;          // the scanlines the header announces: a stream that inflates to more is damaged (or a decompression bomb)
+    void room(size_t more) { if (out.size() + more > limit) bad("compressed stream holds more than the image's scanlines"); }
     [[noreturn]] void bad(const char* what) { fail(std::string("PNG: ") + what + ": " + file); }
     int bits(int need)
     {
@@ -344,7 +346,7 @@ struct Inflater {
         for (;;)
         {
             int sym = decode(lencode);
-            if (sym < 256) { out.push_back((uint8_t)sym); continue; }
+            if (sym < 256) { room(1); out.push_back((uint8_t)sym); continue; }
             if (sym == 256) return;
             sym -= 257;
             if (sym >= 29) bad("invalid length symbol");
@@ -353,6 +355,7 @@ struct Inflater {
             if (ds >= 30) bad("invalid distance symbol");
             const size_t dist = (size_t)dists[ds] + (size_t)bits(dext[ds]);
             if (dist > out.size()) bad("distance reaches before the start of the output");
+            room((size_t)len);
             for (int k = 0; k < len; k++) out.push_back(out[out.size() - dist]);
         }
     }
@@ -374,6 +377,7 @@ struct Inflater {
                 const unsigned len = in[pos] | (in[pos + 1] << 8), nlen = in[pos + 2] | (in[pos + 3] << 8);
                 pos += 4;
                 if ((len ^ 0xFFFFu) != nlen || pos + len > n) bad("stored block is damaged");
+                room((size_t)len);
                 out.insert(out.end(), in + pos, in + pos + len); pos += len;
             }
             else if (type == 1)
@@ -474,10 +478,26 @@ Image load_png(const std::string& file)
     if (depth == 16) fail("PNG: 16 bits per sample are not supported: " + file);
     if (!depthOk) fail("PNG: bit depth " + std::to_string(depth) + " is not valid for colour type " + std::to_string(ctype) + ": " + file);
     if (ctype == 3 && (plte.empty() || plte.size() % 3 != 0)) fail("PNG: palette image without a valid PLTE chunk: " + file);
+    const int bitsPerPixel = channels * depth, bpp = std::max(1, bitsPerPixel / 8);
+    // bytes of filtered scanlines the header announces (per Adam7 pass: rows x (1 + stride)); nothing is allocated for the picture
+    // before the stream has delivered them, and the stream may not deliver more
+    size_t expected = 0;
+    {
+        static const uint32_t px0[7] = {0, 4, 0, 2, 0, 1, 0}, py0[7] = {0, 0, 4, 0, 2, 0, 1}, pdx[7] = {8, 8, 4, 4, 2, 2, 1}, pdy[7] = {8, 8, 8, 4, 4, 2, 2};
+        auto add = [&](uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) {
+            if (x0 >= w || y0 >= h) return;
+            const size_t pw = (w - x0 + dx - 1) / dx, ph = (h - y0 + dy - 1) / dy;
+            expected += ph * (1 + (pw * (size_t)bitsPerPixel + 7) / 8);
+        };
+        if (interlace) for (int i = 0; i < 7; i++) add(px0[i], py0[i], pdx[i], pdy[i]);
+        else add(0, 0, 1, 1);
+    }
+    if (expected > ((size_t)1 << 30)) fail("PNG: image larger than 1 GiB of scanlines: " + file);
     Inflater inf{idat.data(), idat.size(), 0, 0, 0, file, {}};
+    inf.limit = expected;
     inf.run();
     const std::vector<uint8_t>& raw = inf.out;
-    const int bitsPerPixel = channels * depth, bpp = std::max(1, bitsPerPixel / 8);
+    if (raw.size() < expected) fail("PNG: image data ends early: " + file);
     Image img; img.w = (int)w; img.h = (int)h; img.bgra.assign((size_t)w * h * 4, 0);
     auto put = [&](uint32_t x, uint32_t y, const uint8_t* line, uint32_t xi) {       // sample(s) of pixel xi of a defiltered scanline
         uint8_t s[4] = {0, 0, 0, 255};

@@ -1761,7 +1761,14 @@ try {
             d.tl_ok = tl_shared_bytes(d.dtl.tlBytesMax, d.dtl.redLds, histBins) <= (size_t)d.max_lds;
         }
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
-        if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once)) return rcB;
+        if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once))
+        {   // the second tree is an accelerator, not part of the scene: without memory for it the walks use the uploaded tree
+            if (rcB != HRT_ERR_OUT_OF_MEMORY) return rcB;
+            (void)hipGetLastError();
+            for (int i = 0; i < 18; i++) { if (d.tl2mem[i]) (void)hipFree(d.tl2mem[i]); d.tl2mem[i] = nullptr; }
+            d.tl2 = TlasDevice{}; d.any_ok = false; d.any_built = false; d.ordX = d.ordP = 0;
+            c->err.clear();
+        }
     }
     c->scene_ready = true;
     return HRT_OK;
@@ -1985,7 +1992,9 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
 #ifdef HRT_NO_ANY_TREE             // A/B
     return HRT_OK;
 #endif
-    if (!c->packed_ok || c->packed_feat != 0 || c->n_inst < kAnyTreeMinInstances || !d.dpacked.tlasX || !instOnce || nSlots != c->n_inst) return HRT_OK;
+    // own_in_world: the second tree's leaf boxes are unions of the instances' worldBounds, and its exactness argument needs every instance's
+    // own box inside them (an instance whose BLAS the position-indexed builder put over another sphere, Scene.cs:386-395, breaks that)
+    if (!c->packed_ok || c->packed_feat != 0 || c->n_inst < kAnyTreeMinInstances || !d.dpacked.tlasX || !instOnce || nSlots != c->n_inst || !c->own_in_world) return HRT_OK;
     int rc = ensure_lbvh_scratch(c, d);
     if (rc != HRT_OK) return rc;
     TlasDevice T = d.tl;                                        // inputs, capacities, temporaries and LBVH scratch are shared; outputs are its own

@@ -305,7 +305,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                 {
                     if (ANY) { occl = true; mode = M_DONE; }
                     else { tObj = t; iprim = p; }
-                    if (EXISTS && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }   // what the fold at the end of this BLAS would accept (:65-77)
+                    if (EXISTS && tObj < 1e29f && tObj / iscale < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }   // what the fold at the end of this BLAS would accept (:65-77) AND the caller reads as a hit (a world t in [1e29, 1e30) is a miss: the walk goes on)
                 }
             }
             else
@@ -348,7 +348,7 @@ HRT_D void walk_queue(const TracerPackedT<FEAT>& tr, const TracerPackedT<FEAT>& 
                                     accept = !(alpha < mat->AlphaCutoff);
                                 }
                                 if (accept) { tObj = t; iprim = bj; }
-                                if (EXISTS && accept && tObj < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }
+                                if (EXISTS && accept && tObj < 1e29f && tObj / iscale < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = M_DONE; }
                             }
                         }
                         else if (!(t <= 0.001f || t >= lim))

@@ -347,7 +347,7 @@ HRT_D void walk_tl(const TracerPackedT<FEAT>& tr, const DTreelets& T, const TlQu
                                 accept = !(alpha < mat->AlphaCutoff);
                             }
                             if (accept) { tObj = t; iprim = bj; }
-                            if (EXISTS && accept && tObj / iscale < 1e29f && tObj / iscale < bestT)
+                            if (EXISTS && accept && tObj < 1e29f && tObj / iscale < 1e29f && tObj / iscale < bestT)
                             { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = T_DONE; }
                         }
                     }
@@ -389,7 +389,7 @@ HRT_D void walk_tl(const TracerPackedT<FEAT>& tr, const DTreelets& T, const TlQu
                 {
                     if (ANY) { occl = true; mode = T_DONE; }
                     else { tObj = t; iprim = p; }
-                    if (EXISTS && tObj / iscale < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = T_DONE; }
+                    if (EXISTS && tObj < 1e29f && tObj / iscale < 1e29f && tObj / iscale < bestT) { bestT = tObj / iscale; bestTObj = tObj; bestSlot = islot; bestPrim = iprim; mode = T_DONE; }
                 }
                 bj++;
                 if (mode == T_BLEAF && bj == bend) { cur = bskip; mode = leafRet; after_step(); }

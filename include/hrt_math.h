@@ -44,10 +44,25 @@
 HRT_HD uint32_t hrt_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 HRT_HD float    hrt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* ---- min / max -------------------------------------------------------------- */
+/* ---- min / max --------------------------------------------------------------
+ * WHICH DEVICE THE CONTRACT RESTATES.  north_star's parity target is the reference on ILGPU's CPUAccelerator, where kernel code
+ * runs as managed IL and XMath.Min / Max are .NET's Math.Min / Max: IEEE 754-2019 minimum / maximum, a NaN operand is RETURNED.
+ * The shipped reference only runs on ILGPU's PTX backend (CudaAccelerator, Engine/RTRenderer.cs:66-68), where they are
+ * min.f32 / max.f32: minNum / maxNum, a NaN operand is DROPPED -- which is also what gfx950's v_min_f32 / v_max_f32 do in one
+ * instruction.  The two rules differ only when an operand is NaN (call sites in kernel code: IntersectAABB
+ * Engine/SceneDeviceViews.cs:500-513, SafeColor Engine/RTRay.cs:651-653, the clamps of the samplers and of ReSTIR).
+ * Decision: kernels and oracle evaluate the minNum rule (hrt_fmin / hrt_fmax below); -DHRT_KERNEL_MINMAX_DOTNET builds the
+ * oracle with the CPUAccelerator rule instead (oracle/liborc_dotnet.so), and tests/test_minmax_rule.py renders the golden
+ * fixtures and the strips of BASELINE configs 3 / 4 / 5 under both and requires byte-equal outputs: no NaN reaches a min / max on
+ * any BASELINE frame, so the choice is immaterial there.  It is NOT immaterial on hostile inputs (NaN centres, lights, transforms:
+ * the same test counts the hostile frames that differ); there "identical to the oracle" means identical under the minNum rule. */
+HRT_HD float hrt_host_fmin(float a, float b);
+HRT_HD float hrt_host_fmax(float a, float b);
 HRT_HD float hrt_fmin(float a, float b)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(HRT_KERNEL_MINMAX_DOTNET)
+    return hrt_host_fmin(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fminf(a, b);                 /* v_min_f32 */
 #else
     if (a < b) return a;
@@ -58,7 +73,9 @@ HRT_HD float hrt_fmin(float a, float b)
 }
 HRT_HD float hrt_fmax(float a, float b)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(HRT_KERNEL_MINMAX_DOTNET)
+    return hrt_host_fmax(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fmaxf(a, b);                 /* v_max_f32 */
 #else
     if (a > b) return a;

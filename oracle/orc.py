@@ -12,6 +12,8 @@ from ilgpu_raytracing_amd import _types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_VARIANT = ""          # "" = liborc.so; "dotnet" = liborc_dotnet.so (kernel min / max by the CPUAccelerator rule, include/hrt_math.h)
+_LIBS = {}
 
 
 def build(force=False):
@@ -23,12 +25,23 @@ def build(force=False):
     return so
 
 
+def set_variant(name=""):
+    """Switches every function of this module to another build of the oracle ("" = the contract's; "dotnet")."""
+    global _LIB, _VARIANT
+    _LIBS[_VARIANT] = _LIB
+    _VARIANT = name
+    _LIB = _LIBS.get(name)
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liborc.so")
-        if not os.path.exists(so):
-            build()
+        so = os.path.join(_HERE, "liborc%s.so" % ("_" + _VARIANT if _VARIANT else ""))
+        if not os.path.exists(so) or (_VARIANT and os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "orc_kernels.hpp"))):
+            if _VARIANT:
+                subprocess.check_call(["make", "-C", _HERE, "liborc_%s.so" % _VARIANT], stdout=subprocess.DEVNULL)
+            else:
+                build()
         L = C.CDLL(so)
         L.orc_render_frame.restype = C.c_int
         L.orc_render_frame.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.FrameParams), C.c_int, C.c_int, C.c_int, C.c_int,

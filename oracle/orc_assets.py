@@ -305,6 +305,10 @@ def load_png(path):
 
     at = 0
     passes = [(0, 0, 1, 1)] if lace == 0 else [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    # a stream that inflates to more than the scanlines the header announces is refused (the product stops a decompression bomb there)
+    expected = sum(((h - y0 + dy - 1) // dy) * (1 + (((w - x0 + dx - 1) // dx) * bits + 7) // 8) for x0, y0, dx, dy in passes if x0 < w and y0 < h)
+    if len(raw) > expected:
+        raise FormatError("PNG stream holds more than the image's scanlines")
     for x0, y0, dx, dy in passes:
         if x0 >= w or y0 >= h:
             continue

@@ -154,3 +154,49 @@ def test_equal_distance_instances_on_the_second_tree(orc, hrt_lib):
         assert st.k[1].as_dict() == ost.k[1].as_dict()
     finally:
         r.close()
+
+
+def test_second_tree_is_not_built_over_stale_world_bounds(orc, renderer):
+    """400 one-sphere instances whose uploaded tree is nested and lists every instance once, but ONE instance's own box (its
+    one-node BLAS, over a sphere that sits between the old places of the two instances of its leaf) lies outside its worldBounds.  The
+    reference walks the uploaded leaf -- whose box holds the sphere -- and sees it; a second tree built from the worldBounds would not.
+    Every organisation must show the oracle's picture (the upload path, where round 2 checked own_in_world only after device updates)."""
+    cfg = scenes.Config("stale", 0, 0, 0, (0.0, 2.2, 7.5), (0.0, 0.6, 0.0))
+    w, h, spp = 160, 100, 2
+    so = orc.OrcScene(); scenes.build_random_spheres(so, 400, seed=0x5EED, extent=3.0)
+    arrs = {k: v.copy() for k, v in so.arrays().items()}
+    tn, ti, inst, bn, sp = arrs["tlasNodes"], arrs["tlasInstanceIndices"], arrs["instances"], arrs["blasNodes"], arrs["spheres"]
+    best = None
+    for n in tn:
+        if n["count"] != 2: continue
+        a, b = int(ti[n["first"]]), int(ti[n["first"] + 1])
+        if 0 in (a, b): continue                                     # not the ground sphere
+        sa, sb = sp[int(arrs["spherePrimIdx"][bn[inst[a]["blasRoot"]]["first"]])], sp[int(arrs["spherePrimIdx"][bn[inst[b]["blasRoot"]]["first"]])]
+        ca = np.array([sa["center"][f] for f in "XYZ"]); cb = np.array([sb["center"][f] for f in "XYZ"])
+        gap = np.linalg.norm(ca - cb) - sa["radius"] - sb["radius"]
+        if best is None or gap > best[0]: best = (gap, a, b, ca, cb, min(sa["radius"], sb["radius"]))
+    gap, a, b, ca, cb, rmin = best
+    assert gap > 0.1, "no leaf of two well separated spheres in this scene"
+    sid = int(arrs["spherePrimIdx"][bn[inst[a]["blasRoot"]]["first"]])
+    mid, rad = ((ca + cb) * 0.5).astype(np.float32), np.float32(min(rmin, gap * 0.4))
+    for k, f in enumerate("XYZ"):
+        sp["center"][f][sid] = mid[k]
+        bn["boundsMin"][f][inst[a]["blasRoot"]] = mid[k] - rad
+        bn["boundsMax"][f][inst[a]["blasRoot"]] = mid[k] + rad
+    sp["radius"][sid] = rad
+    sp["albedo"]["X"][sid], sp["albedo"]["Y"][sid], sp["albedo"]["Z"][sid] = 0.95, 0.1, 0.1
+    sp["material"]["Kd"]["X"][sid], sp["material"]["Kd"]["Y"][sid], sp["material"]["Kd"]["Z"][sid] = 0.95, 0.1, 0.1
+    desc, keep = T.scene_desc_from_arrays(arrs)
+    p = scenes.frame_params(cfg, *H.host_funcs("orc", orc), width=w, height=h, spp=spp)
+    ref, o = T.alloc_outputs(w, h)
+    orc.render_frame(desc, p, o, None)
+    renderer.commit(desc)
+    try:
+        for flags in (0, T.FLAG_STREAMED, T.FLAG_STREAMED | T.FLAG_COUNTERS, T.FLAG_MEGAKERNEL):
+            renderer.reset_history()
+            pg = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+            got, og = T.alloc_outputs(w, h)
+            renderer.render_params(pg, og, flags=flags)
+            H.assert_outputs_equal(ref, got)
+    finally:
+        s2 = engine.Scene(); scenes.build_config2(s2); renderer.commit(s2)

@@ -457,6 +457,22 @@ def test_png_errors_are_loud(tmp_path):
     d16 = bytearray(open(deep, "rb").read()); d16[24] = 16
     d16[29:33] = struct.pack(">I", zlib.crc32(bytes(d16[12:29])) & 0xFFFFFFFF)
     cases["16bit"] = bytes(d16)
+    # a stream that inflates to more than the header's scanlines (the shape of a decompression bomb), and a 3-row stream under a
+    # header that announces 32768 x 32768: both refused, the second without allocating the 4 GiB picture first
+    def rechunk(blob, ihdr=None, idat=None):
+        out, p = blob[:8], 8
+        while p < len(blob):
+            n = struct.unpack(">I", blob[p:p + 4])[0]; typ = blob[p + 4:p + 8]; body = blob[p + 8:p + 8 + n]
+            if typ == b"IHDR" and ihdr is not None: body = ihdr(body)
+            if typ == b"IDAT" and idat is not None: body = idat(body)
+            out += struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+            p += 12 + n
+        return out
+    one = str(tmp_path / "one.png")
+    K.write_png(one, np.zeros((4, 4, 3), int), 2, filters=[0], idat_split=1)
+    blob1 = open(one, "rb").read()
+    cases["surplus"] = rechunk(blob1, idat=lambda b: zlib.compress(zlib.decompress(b) + bytes(4096)))
+    cases["bomb_header"] = rechunk(blob1, ihdr=lambda b: struct.pack(">II", 32768, 32768) + b[8:])
     for k, blob in cases.items():
         p = str(tmp_path / (k + ".png"))
         open(p, "wb").write(blob)
