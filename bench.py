@@ -26,9 +26,14 @@ Rank 0 prints ONE JSON line (schema: task contract) with these extra objects:
                   time against 8 TB/s, plus the compulsory bytes (per-pixel arrays the launch must read and write).
                   `traffic` = those measured bytes.  `algorithmic_bytes_per_launch` (every node /
                   primitive fetch of the reference algorithm priced as memory traffic) is informational only.
-                  PMC counters are collected IN THIS RUN by three `rocprofv3 --pmc ... --kernel-trace` passes over
-                  `python bench.py --pmc-child` (N = 1 only; `pmc_source` says so), or, when rocprofv3 is not
-                  usable, read from the committed profiles/r02_pmc_config<N>.json (`pmc_source.kind = "file"`).
+                  `useful_lane_frac` = frac x lane_utilisation (issue slots x live lanes); `frac_issue_cycles` weights the
+                  quarter-rate instructions (PMC SQ_INSTS_VALU_TRANS_F32) with the 8 cycles they hold a SIMD.
+                  PMC counters are collected IN THIS RUN by `rocprofv3 --pmc ... --kernel-trace` passes over
+                  `python bench.py --pmc-child` (`pmc_source` says so), or, at N = 1 when rocprofv3 is not usable, read from
+                  the committed profiles/r03_pmc_config<N>.json (`pmc_source.kind = "file"`).  At N > 1 rank 0 profiles its
+                  OWN tile and prices it against ONE GPU's peak (never single-GPU counts against N x the peak); without
+                  rocprofv3 frac is null there.  The extras (configs 3 / 4 / 5) carry a roofline of their own (N = 1; the
+                  4K configs' PMC child renders 8 spp and the counts are scaled to the timed sample count).
   cpu_baseline -- the CPU oracle ("port": this repo's restatement of the reference kernels; the C#
                   reference cannot be built here) timed on the host cores over a bounded sample of
                   the same workload (N=1, rank 0 only).
@@ -57,6 +62,12 @@ CLOCK_GHZ = 2.4                # max clock (spec); the clock held under load is 
 VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0     # wave64 VALU instructions per ns over the chip: one per 2 cycles per SIMD-32
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
+# optional fourth pass: quarter-rate (transcendental unit) instructions -- v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos, which the
+# IEEE division and square-root sequences of these kernels are built around.  A wave64 one occupies its SIMD for 8 cycles instead of 2.
+PMC_TRANS = ("SQ_INSTS_VALU_TRANS_F32",)
+# sample counts of the PMC child for the 4K configs (their counters are linear in spp: every sample batch does the same work;
+# the roofline scales the counts to the timed frame's spp and says so)
+PMC_CHILD_SPP = {4: 8, 5: 8}
 
 
 def algorithmic_bytes(c, n_pixels, launch):
@@ -140,8 +151,9 @@ def pmc_child_frames(cfg_id):
     return 1 + (3 if cfg.spp * cfg.width <= 16 * 1920 else 1)
 
 
-def pmc_child(cfg_id, spp):
-    """The program the rocprofv3 passes run: the same production frames as the timed region (no torch, no counting frame)."""
+def pmc_child(cfg_id, spp, strips=None):
+    """The program the rocprofv3 passes run: the same production frames as the timed region (no torch, no counting frame).
+    strips = (n, i): the tile of rank i of n (what that rank renders in an N-GPU run)."""
     from ilgpu_raytracing_amd import _types as T, engine, scenes
     cfg = scenes.CONFIGS[cfg_id]
     r = engine.RTRenderer([0])
@@ -150,12 +162,12 @@ def pmc_child(cfg_id, spp):
     r.commit(s)
     p = scenes.frame_params(cfg, engine.camera_look_at, engine.bake_camera_derived, engine.sun_direction, spp=spp or None)
     for _ in range(pmc_child_frames(cfg_id)):
-        r.render_params(p, None, flags=T.FLAG_NO_SYNC)
+        r.render_params(p, None, flags=T.FLAG_NO_SYNC, strips=strips)
     r.synchronize()
     r.close()
 
 
-def measure_pmc(cfg_id, spp, out_dir, timeout_s=240):
+def measure_pmc(cfg_id, spp, out_dir, timeout_s=240, strips=None):
     """Three separate rocprofv3 --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md) over
     `bench.py --pmc-child`; kernel trace only.  Returns per-kernel per-frame sums, or None."""
     import collections
@@ -167,14 +179,18 @@ def measure_pmc(cfg_id, spp, out_dir, timeout_s=240):
     os.makedirs(out_dir, exist_ok=True)
     per = collections.defaultdict(lambda: collections.defaultdict(float))        # kernel -> counter -> sum over dispatches
     disp = collections.defaultdict(int)
-    for i, ctrs in enumerate(PMC_PASSES):
+    for i, ctrs in enumerate(PMC_PASSES + (PMC_TRANS,)):
+        optional = i >= len(PMC_PASSES)
         d = os.path.join(out_dir, "pass%d" % i)
         shutil.rmtree(d, ignore_errors=True)
         cmd = [rocprof, "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                                                 sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(cfg_id)] + (["--spp", str(spp)] if spp else [])
+                                                 sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(cfg_id)] + (["--spp", str(spp)] if spp else []) \
+            + (["--pmc-strips", "%d,%d" % strips] if strips else [])
         try:
             subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False, timeout=timeout_s)
         except Exception:
+            if optional:
+                break
             return None
         rows = 0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -188,6 +204,8 @@ def measure_pmc(cfg_id, spp, out_dir, timeout_s=240):
                 if i == 0:
                     disp[k] += 1
         if rows == 0:
+            if optional:
+                break                   # this rocprofv3 does not know the counter: frac stays unweighted and says so
             return None
     frames = pmc_child_frames(cfg_id)              # (not counted from dispatches: a frame of the fused kernel can be one launch or two)
     kernels = {}
@@ -223,15 +241,18 @@ def is_counting_kernel(name):
     return len(args) > pos and args[pos] == "true"
 
 
-def pmc_for(cfg_id, spp, allow_run, out_dir):
+def pmc_for(cfg_id, spp, allow_run, out_dir, strips=None, allow_file=True):
     """(per-launch counter sums of the path-trace stage, source description).  Measured now if allowed, else the committed file."""
     src = None
-    res = measure_pmc(cfg_id, spp, out_dir) if allow_run else None
+    res = measure_pmc(cfg_id, spp, out_dir, strips=strips) if allow_run else None
     if res is not None:
-        src = {"kind": "measured in this run", "how": "3 rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, GRBM_GUI_ACTIVE) + --kernel-trace over `bench.py --pmc-child --config %d`" % cfg_id,
+        src = {"kind": "measured in this run", "how": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, GRBM_GUI_ACTIVE | SQ_INSTS_VALU_TRANS_F32) + --kernel-trace over `bench.py --pmc-child --config %d`%s%s"
+                      % (cfg_id, " --spp %d" % spp if spp else "", " --pmc-strips %d,%d" % strips if strips else ""),
                "frames_profiled": res["frames"]}
-    else:
-        path = os.path.join(ROOT, "profiles", "r02_pmc_config%d.json" % cfg_id)
+        if strips:
+            src["tile"] = "strips %d of %d: the tile ONE rank renders, priced against ONE GPU's peak" % (strips[1], strips[0])
+    elif allow_file and not strips:
+        path = os.path.join(ROOT, "profiles", "r03_pmc_config%d.json" % cfg_id)
         if os.path.exists(path):
             try:
                 j = json.load(open(path))
@@ -243,6 +264,7 @@ def pmc_for(cfg_id, spp, allow_run, out_dir):
                 res = None
     if res is None:
         return None, {"kind": "none"}
+    src["child_spp"] = spp or None
     stage = {}
     names = []
     for k, cs in res["kernels"].items():
@@ -392,24 +414,34 @@ class Runner:
                 fb.close()
 
 
-def roofline_of(res, pmc, pmc_src, world):
-    """VALU-issue roofline of the path-trace stage + its measured HBM picture (see the module docstring)."""
+def roofline_of(res, pmc, pmc_src, world, count_scale=1.0, tile_of=1):
+    """VALU-issue roofline of the path-trace stage + its measured HBM picture (see the module docstring).
+    world: GPUs whose peak the counts are priced against (1 when the counts are those of one rank's tile);
+    count_scale: timed spp / spp of the PMC child (counters are linear in the sample count);
+    tile_of: N when the counts are those of ONE rank's tile of an N-rank frame (compulsory and algorithmic bytes are then the tile's)."""
     cfg = res["cfg"]
     kernel = ("hrt_path_trace_kernel<TracerFlat> (fused; sample-group split kernel + resolve on small tiles)" if res["fused"]
               else "path-trace stage, streamed: hrt_wf_{shade,walk_shadow,walk_closest,finish,resolve}_kernel")
     launch_s = res["path_ms"] * 1e-3
-    compulsory = res["pixels"] * (48 + 12 + 44)      # G-buffer read 48 B + framebuffer write 12 B + reservoir write <= 44 B per pixel
+    compulsory = res["pixels"] * (48 + 12 + 44) / float(tile_of)      # G-buffer read 48 B + framebuffer write 12 B + reservoir write <= 44 B per pixel
     out = {"bound": "valu", "kernel": kernel, "launch_ms": round(res["path_ms"], 4),
            "unit": "G wave64 VALU instructions / s",
            "peak": round(VALU_PEAK_GINST * world, 1),
            "peak_is": "%d SIMD-32 x %.1f GHz / 2 cycles per wave64 VALU instruction, x %d GPU(s)" % (N_SIMD, CLOCK_GHZ, world),
            "achieved": None, "frac": None, "traffic": None,
-           "algorithmic_bytes_per_launch": int(res["alg_bytes"]),
+           "algorithmic_bytes_per_launch": int(res["alg_bytes"] / float(tile_of)),
            "algorithmic_note": "SURVEY 8d figure (reference struct sizes x work counters: every node / primitive fetch priced as memory traffic); "
                                "informational only -- the trees are cache-resident, this is not HBM traffic and is never used as frac",
            "pmc_source": pmc_src}
+    if tile_of > 1:
+        out["priced"] = "rank 0's tile (1/%d of the frame, interleaved 8-row strips) against ONE GPU's peak over the slowest rank's launch time" % tile_of
     if pmc is not None and launch_s > 0:
-        stg = pmc["stage"]
+        stg = dict(pmc["stage"])
+        if count_scale != 1.0:
+            for k_, v_ in list(stg.items()):
+                if isinstance(v_, float) and k_ != "dispatches_per_frame":
+                    stg[k_] = v_ * count_scale
+            out["counts_scaled_by"] = round(count_scale, 4)
         insts = stg.get("SQ_INSTS_VALU", 0.0)
         achieved = insts / launch_s / 1e9
         out["achieved"] = round(achieved, 2)
@@ -417,6 +449,16 @@ def roofline_of(res, pmc, pmc_src, world):
         out["valu_insts_per_launch"] = int(insts)
         if stg.get("SQ_ACTIVE_INST_VALU"):
             out["lane_utilisation"] = round(stg.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * stg["SQ_ACTIVE_INST_VALU"]), 4)
+            out["useful_lane_frac"] = round(out["frac"] * out["lane_utilisation"], 4)       # issue slots x live lanes: what frac hides
+        # issue-CYCLE occupancy: a quarter-rate instruction holds its SIMD four times as long as the others
+        trans = stg.get("SQ_INSTS_VALU_TRANS_F32")
+        if trans is not None and insts > 0:
+            out["trans_insts_per_launch"] = int(trans)
+            out["frac_issue_cycles"] = round((insts + 3.0 * trans) / launch_s / 1e9 / (VALU_PEAK_GINST * world), 4)
+            out["frac_issue_cycles_is"] = "(VALU instructions + 3 x quarter-rate ones) x 2 cycles / (SIMD-cycles of the launch): v_rcp / v_rsq / v_sqrt ... occupy a SIMD for 8 cycles per wave64"
+        else:
+            out["frac_issue_cycles"] = None
+            out["frac_issue_cycles_is"] = "not measured: this rocprofv3 has no SQ_INSTS_VALU_TRANS_F32; frac prices every instruction at the full rate (2 cycles)"
         if stg.get("SQ_WAVE_CYCLES"):
             out["wave_time_waiting"] = round(stg.get("SQ_WAIT_ANY", 0.0) / stg["SQ_WAVE_CYCLES"], 4)
         traffic = stg.get("hbm_read_bytes", 0.0) + stg.get("hbm_write_bytes", 0.0)
@@ -459,11 +501,12 @@ def main():
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto", help="auto: collect the roofline's PMC counters with rocprofv3 passes in this run (N = 1)")
     ap.add_argument("--extras", type=int, default=1, help="1: also run BASELINE configs 3, 4 and 5 at their stated size and spp (fewer steps) into `extra`")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-strips", default="", help=argparse.SUPPRESS)
     ap.add_argument("--save-pmc", default=None, help="write the measured per-kernel PMC sums to this JSON (profiles/r02_pmc_config<N>.json)")
     args = ap.parse_args()
 
     if args.pmc_child:
-        pmc_child(args.config, args.spp)
+        pmc_child(args.config, args.spp, tuple(int(v) for v in args.pmc_strips.split(",")) if args.pmc_strips else None)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -474,21 +517,36 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
-    # PMC passes first: child processes, before this process touches the GPU
+    # PMC passes first: child processes, before this process touches the GPU.
+    # N = 1: the whole frame, measured now (or the committed profile when rocprofv3 is unusable).
+    # N > 1: rank 0 profiles ITS OWN tile (strips (N, 0): interleaved 8-row strips, every rank's tile is statistically the same; small
+    #        tiles run the sample-group split kernel, which is what gets counted) and prices it against ONE GPU's peak over the slowest
+    #        rank's launch time.  Never the N = 1 counts against N x the peak.
     pmc = None
     pmc_src = {"kind": "none"}
+    extra_pmc = {}
     if rank == 0:
-        # N = 1: measured now.  N > 1: the committed N = 1 counts (the instructions of a frame do not depend on how its strips are
-        # dealt to the ranks, up to the sample-group split of small tiles), priced against N x the peak
-        pmc_dir = os.path.join(ROOT, "gpurun_out", "bench_pmc_config%d" % args.config)
         have_gpu = os.path.exists("/dev/kfd")
-        pmc, pmc_src = pmc_for(args.config, args.spp, world == 1 and args.pmc == "auto" and have_gpu, pmc_dir)
-        if world > 1 and pmc is not None:
-            pmc_src = dict(pmc_src, note="counts of the N = 1 frame; at N > 1 they are spread over the ranks")
+        run_ok = args.pmc == "auto" and have_gpu
+        pmc_dir = os.path.join(ROOT, "gpurun_out", "bench_pmc_config%d%s" % (args.config, "_tile%d" % world if world > 1 else ""))
+        child_spp = args.spp or PMC_CHILD_SPP.get(args.config, 0)
+        pmc, pmc_src = pmc_for(args.config, child_spp, run_ok, pmc_dir, strips=(world, 0) if world > 1 else None, allow_file=world == 1)
+        if world > 1 and pmc is None:
+            pmc_src = {"kind": "none", "reason": "N > 1 and no in-run PMC of rank 0's tile (rocprofv3 unusable): frac is not computed rather than priced from single-GPU counts"}
         if args.save_pmc and pmc is not None and pmc_src.get("kind") != "file":
-            raw = dict(pmc["raw"], config=args.config, spp=args.spp or None, sources_sha1=sources_sha1(),
+            raw = dict(pmc["raw"], config=args.config, spp=child_spp or None, sources_sha1=sources_sha1(),
                        note="per-kernel sums per frame; FETCH_SIZE / WRITE_SIZE in KiB (hbm_*_bytes = x1024); rocprofv3 --pmc passes of `bench.py --pmc-child`")
             json.dump(raw, open(args.save_pmc, "w"), indent=1, sort_keys=True)
+        if world == 1 and run_ok and args.extras and args.config == 2 and not args.spp and not args.device_tlas:
+            for cid in (3, 4, 5):          # the extras get their own roofline (4K configs: PMC child at 8 spp, counts scaled to the timed spp)
+                t_p = time.perf_counter()
+                pm, src = pmc_for(cid, PMC_CHILD_SPP.get(cid, 0), True, os.path.join(ROOT, "gpurun_out", "bench_pmc_config%d" % cid), allow_file=False)
+                src["seconds"] = round(time.perf_counter() - t_p, 1)
+                extra_pmc[cid] = (pm, src)
+                if args.save_pmc and pm is not None:
+                    raw = dict(pm["raw"], config=cid, spp=PMC_CHILD_SPP.get(cid) or None, sources_sha1=sources_sha1(),
+                               note="per-kernel sums per frame; FETCH_SIZE / WRITE_SIZE in KiB (hbm_*_bytes = x1024); rocprofv3 --pmc passes of `bench.py --pmc-child`")
+                    json.dump(raw, open(args.save_pmc.replace("config%d" % args.config, "config%d" % cid) if "config%d" % args.config in args.save_pmc else args.save_pmc + ".config%d" % cid, "w"), indent=1, sort_keys=True)
 
     import torch            # loaded first: its bundled HIP runtime is the one the process uses
     import torch.distributed as dist
@@ -532,7 +590,8 @@ def main():
                        "max_depth": cfg.max_depth, "frame": 0, "restir_reuse": False,
                        "tlas": ("rebuilt on the device (LBVH); picture bit-identical to the uploaded tree's: %s" % main_res["same_picture"]) if args.device_tlas else "as uploaded (reference builder)",
                        "parallelism": "row-strips x%d (8-row strips, round-robin)" % world, "rays_per_step": int(main_res["rays"])},
-            "roofline": roofline_of(main_res, pmc, pmc_src, world),
+            "roofline": roofline_of(main_res, pmc, pmc_src, 1, tile_of=world,
+                                    count_scale=(cfg.spp / float(pmc_src["child_spp"])) if pmc_src.get("child_spp") else 1.0),
             "extra": {"primary_kernel_ms": round(main_res["prim_ms"], 4), "path_trace_kernel_ms": round(main_res["path_ms"], 4),
                       "frame_event_ms_min": main_res["frame_ms_min"], "frame_event_ms_median": main_res["frame_ms_median"],
                       "step_ms_with_d2h_gather": round(main_res["d2h_step"] * 1e3, 4),
@@ -551,6 +610,9 @@ def main():
             cid = {"config3": 3, "config4_full_spp": 4, "config5_full_spp": 5}[name]
             cpu = cpu_baseline(cid, res["cfg"], min(6.0, args.cpu_seconds)) if (world == 1 and args.cpu_seconds > 0) else None
             out["extra"][name] = summary_of(res, world, cpu)
+            if cid in extra_pmc:
+                pm, src = extra_pmc[cid]
+                out["extra"][name]["roofline"] = roofline_of(res, pm, src, 1, count_scale=(res["cfg"].spp / float(src["child_spp"])) if src.get("child_spp") else 1.0)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

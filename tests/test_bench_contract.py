@@ -34,6 +34,9 @@ def test_bench_json_line():
     assert h["peak"] == 8000.0 and h["unit"] == "GB/s" and 0.0 < h["frac"] <= 1.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3
     assert abs(r["traffic"] - h["read_bytes"] - h["write_bytes"]) <= 2 and r["traffic"] >= 0.5 * h["compulsory_bytes"]
     assert "algorithmic_bytes_per_launch" in r and 0.0 < r["lane_utilisation"] <= 1.0
+    # what frac hides: idle lanes, and the quarter-rate instructions (the second only where this rocprofv3 has the counter)
+    assert abs(r["useful_lane_frac"] - r["frac"] * r["lane_utilisation"]) < 2e-4
+    assert "frac_issue_cycles" in r and (r["frac_issue_cycles"] is None or r["frac"] <= r["frac_issue_cycles"] <= 1.0)
     assert j["extra"]["frame_event_ms_min"] <= j["extra"]["frame_event_ms_median"]
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
@@ -61,3 +64,23 @@ def test_counting_kernels_are_told_from_production_ones_by_their_count_argument(
              "hrt_wf_resolve_kernel": False}
     for name, want in cases.items():
         assert bench.is_counting_kernel(name) == want, name
+
+
+def test_roofline_scales_child_counts_and_prices_a_tile_against_one_gpu():
+    """The extras' PMC child renders fewer samples than the timed frame (counters are linear in spp), and at N > 1 the counts are
+    those of rank 0's tile: one GPU's peak, the tile's share of the compulsory bytes -- never N x the peak."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from ilgpu_raytracing_amd import scenes
+    res = {"cfg": scenes.CONFIGS[4], "fused": False, "path_ms": 100.0, "pixels": 3840 * 2160, "alg_bytes": 8e9, "rays": 1e9}
+    stage = {"SQ_INSTS_VALU": 1e9, "SQ_ACTIVE_INST_VALU": 1e9, "SQ_THREAD_CYCLES_VALU": 32e9, "SQ_WAVE_CYCLES": 4e9, "SQ_WAIT_ANY": 2e9,
+             "hbm_read_bytes": 1e9, "hbm_write_bytes": 5e8, "SQ_INSTS_VALU_TRANS_F32": 1e8, "kernels": ["k"]}
+    a = bench.roofline_of(res, {"stage": stage}, {"kind": "measured in this run", "child_spp": 8}, 1, count_scale=8.0)
+    assert a["valu_insts_per_launch"] == 8e9 and a["counts_scaled_by"] == 8.0 and a["traffic"] == 12e9
+    assert abs(a["frac"] - 8e9 / 0.1 / 1e9 / bench.VALU_PEAK_GINST) < 1e-4 and abs(a["lane_utilisation"] - 0.5) < 1e-9
+    assert abs(a["useful_lane_frac"] - a["frac"] * 0.5) < 1e-4 and abs(a["frac_issue_cycles"] - a["frac"] * 1.3) < 1e-3
+    b = bench.roofline_of(res, {"stage": stage}, {"kind": "measured in this run"}, 1, tile_of=8)
+    assert b["peak"] == round(bench.VALU_PEAK_GINST, 1) and "tile" in b["priced"]
+    assert b["hbm"]["compulsory_bytes"] == int(3840 * 2160 * 104 / 8) and b["algorithmic_bytes_per_launch"] == int(1e9)
+    c = bench.roofline_of(res, None, {"kind": "none", "reason": "x"}, 1, tile_of=8)
+    assert c["frac"] is None and c["achieved"] is None
