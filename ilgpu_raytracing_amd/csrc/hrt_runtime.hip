@@ -193,6 +193,7 @@ hrt_wf_walk_shadow_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, WfB
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    W = W.at_depth(depth);
     wf_walk_shadow_wave<FEAT, COUNT, ALT, LT>(tr, exact, W, vsel ? W.B : W.A, depth, W.grab + (depth * 2 + 0) * 8, own, C);
     C.flush(counters);
 }
@@ -205,6 +206,7 @@ hrt_wf_walk_closest_kernel(TracerPackedT<FEAT> tr, TracerPackedT<FEAT> exact, Wf
     Cnt<COUNT> C;
     int own = -1;
     if (!chained) { own = wf_range(W.nRanges); if (own < 0) own = W.nRanges; }
+    W = W.at_depth(depth);
     wf_walk_closest_wave<FEAT, COUNT, EXISTS, ALT, LT>(tr, exact, W, depth, W.grab + (depth * 2 + 1) * 8, own, C);
     C.flush(counters);
 }
@@ -219,6 +221,7 @@ __global__ void __launch_bounds__(256, PHASE == 1 ? 2 : 4)
 hrt_tl_walk_kernel(TracerPackedT<FEAT> tr, DTreelets T, TlQueues Q, WfBuffers W, int depth, int histBins, int tlRegion, int round)
 {
     const TlShared sh = tl_shared(tlRegion, T.redLds, histBins);
+    W = W.at_depth(depth);
     {   // the top of the reduced tree stays in LDS for the whole kernel
         float4* red = const_cast<float4*>(sh.red);
         const float4* src = reinterpret_cast<const float4*>(T.red);
@@ -312,7 +315,20 @@ __global__ void __launch_bounds__(256)
 hrt_wf_finish_kernel(TracerPackedT<FEAT> tr, FrameK k, WfBuffers W, int vsel, int depth)
 {
     int range = wf_range(W.nRanges);
+    W = W.at_depth(depth);
     wf_finish_wave<FEAT, COUNT>(tr, k, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range);      // every wave: the four waves of a workgroup pack their survivors together
+}
+
+// finish of bounce `depth` + shade of bounce depth + 1 in one kernel (every bounce but the last): hrt_wavefront.hpp
+template <int FEAT, bool COUNT>
+__global__ void __launch_bounds__(256)
+hrt_wf_finish_shade_kernel(TracerPackedT<FEAT> tr, FrameK k, WfGeom g, DGBuffer gb, DReservoir resPrev, long long nPix, WfBuffers W, int vsel, int depth, unsigned long long* counters)
+{
+    Cnt<COUNT> C;
+    int range = wf_range(W.nRanges);
+    W = W.at_depth(depth);
+    wf_finish_shade_wave<FEAT, COUNT>(tr, k, g, gb, resPrev, nPix, W, vsel ? W.B : W.A, vsel ? W.A : W.B, depth, range, C);
+    C.flush(counters);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1158,6 +1174,8 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nO
     float* m = d.wf_mem[lane];
     auto take = [&](int nplanes, long long stride) { Planes pl; pl.base = m; pl.stride = stride; m += (size_t)nplanes * (size_t)stride; return pl; };
     W.A = take(V_PLANES, cap); W.B = take(V_PLANES, cap); W.R = take(R_PLANES, cap); W.SQ = take(S_PLANES, cap);
+    static_assert(V_POS == 0 && V_LI >= R_PLANES && V_PID >= R_PLANES && R_PLANES >= S_PLANES, "the second request set aliases the vertex planes below V_LI");
+    W.Rn = W.A; W.SQn = W.B; W.pingpong = 0;
     W.sampleLi = take(3, cap); W.stage = take(G_PLANES, cap);
     W.accum.base = d.wf_accum; W.accum.stride = nOrd;
     W.cntA = d.wf_cnt[lane]; W.cntS = d.wf_cnt[lane] + (size_t)(maxDepth + 1) * (size_t)nRanges;
@@ -1305,6 +1323,13 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const dim3 gridW((unsigned)std::min<long long>((nRanges + 3) / 4, (long long)d.n_cu * (nLanes >= 2 ? kWalkBlocksPerCU2 : kWalkBlocksPerCU)));
     static const bool forkShadow = HRT_ENV("HRT_NO_FORK") == nullptr;       // A/B knob
     static const bool forkStatic = HRT_ENV("HRT_FORK_STATIC") != nullptr;   // A/B knob
+    // finish of a bounce and shade of the next one as ONE kernel (the vertex never round-trips through its 22 planes): sphere-instance scenes
+    // (config 3: path stage -3.6 %, HBM traffic 13.6 -> 11.7 GB per frame).  Triangle scenes keep the two kernels: their walks leave the vector
+    // units to the other sample batch's shade / finish kernels, and the fused kernel (111 registers through the fetch-bound half) fills them
+    // worse (config 5 +3 %, config 4 +-0.5 %: profiles/EXPERIMENTS.md)
+    static const int fuseEnv = HRT_ENV("HRT_FUSE") ? atoi(HRT_ENV("HRT_FUSE")) : -1;       // A/B knob
+    const bool fuse = PackedFeat<TR>::value >= 0 && (fuseEnv >= 0 ? fuseEnv != 0 : PackedFeat<TR>::value == 0);
+    for (int j = 0; j < nLanes; j++) Wl[j].pingpong = fuse ? 1 : 0;
     int batch = 0;
     for (int b0 = 0; b0 < spp; b0 += (int)sb, batch++)
     {
@@ -1329,6 +1354,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                 if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, true>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
                 else       hipLaunchKernelGGL((hrt_wf_shade_kernel<false, true>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             }
+            else if (fuse) { }                              // the vertices of this bounce were shaded by the fused finish + shade kernel of the last one
             else if (count) hipLaunchKernelGGL((hrt_wf_shade_kernel<true, false>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             else            hipLaunchKernelGGL((hrt_wf_shade_kernel<false, false>), gridR, block, 0, sMain, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
             if constexpr (PackedFeat<TR>::value >= 0)
@@ -1401,11 +1427,22 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     if (lt3) hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true, false, (F != 0 ? 3 : 2)>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
                     else     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, false, true>), chained ? gridW : gridR, block, 0, st, tr, tr, W, depth, chained, cnt1);
                 };
+                // the winners' shading: on the last bounce the paths end (wf_finish); before it the next vertex is shaded in the same kernel
+                const bool finalBounce = depth + 1 >= k.maxDepth;
+                auto launch_finish = [&](const TR& trF) {
+                    if (count)
+                    {
+                        if (finalBounce || !fuse) hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, sMain, trF, k, W, vsel, depth);
+                        else hipLaunchKernelGGL((hrt_wf_finish_shade_kernel<F, true>), gridR, block, 0, sMain, trF, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                    }
+                    else if (finalBounce || !fuse) hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trF, k, W, vsel, depth);
+                    else hipLaunchKernelGGL((hrt_wf_finish_shade_kernel<F, false>), gridR, block, 0, sMain, trF, k, g, d.gb, resPrev, nPix, W, vsel, depth, cnt1);
+                };
                 if (count)
                 {
                     hipLaunchKernelGGL((hrt_wf_walk_shadow_kernel<F, true>), chained ? gridW : gridR, block, 0, sMain, tr, tr, W, vsel, depth, chained, cnt1);
                     hipLaunchKernelGGL((hrt_wf_walk_closest_kernel<F, true>), chained ? gridW : gridR, block, 0, sMain, tr, tr, W, depth, chained, cnt1);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, true>), gridR, block, 0, sMain, tr, k, W, vsel, depth);
+                    launch_finish(tr);
                 }
                 else if ((chained || forkStatic) && forkShadow)
                 {   // the two walks of a bounce are independent (shadow requests vs bounce rays) and both are persistent
@@ -1417,13 +1454,13 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
                     launch_shadow(sSide);
                     HIPCHK(c, hipEventRecord(d.evLane[lane][1], sSide));
                     HIPCHK(c, hipStreamWaitEvent(sMain, d.evLane[lane][1], 0));
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trFin, k, W, vsel, depth);
+                    launch_finish(trFin);
                 }
                 else
                 {
                     launch_shadow(sMain);
                     launch_closest(sMain);
-                    hipLaunchKernelGGL((hrt_wf_finish_kernel<F, false>), gridR, block, 0, sMain, trFin, k, W, vsel, depth);
+                    launch_finish(trFin);
                 }
                 if (tlRc != HRT_OK) return tlRc;
             }

@@ -41,7 +41,7 @@ namespace hrt {
 #define HRT_RANGE 384
 #endif
 constexpr int kRange = HRT_RANGE;            // slots per range (one wave owns one range); 256 / 384 / 512 / 1024 measured, DESIGN.md 8
-static_assert(kRange % 64 == 0 && kRange <= 65536, "a range is a whole number of waves; shade tags a vertex with its request's offset in 16 bits");
+static_assert(kRange % 64 == 0 && 4 * kRange <= 65536, "a range is a whole number of waves; shade tags a vertex with its request's offset in 16 bits");
 
 struct Planes {                              // plane p of slot i = base[p * stride + i]
     float* base; long long stride;
@@ -64,7 +64,7 @@ enum { V_POS = 0, V_NRM = 3, V_ALB = 6, V_IDIR = 9, V_T = 12, V_LI = 15, V_RNG =
 // ray request written by wf_shade for the same slot
 // RQ_A = (o.xyz, d.x)  RQ_B = (d.yz, flags, rng)  RQ_H = raw winner of the closest-hit walk (t, tObj, leaf slot, primitive): 16-byte records
 enum { RQ_A = 0, RQ_B = 4, R_T = 8, RQ_H = 11, R_PLANES = 15 };
-enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROTE also in V_MAT bit 17); RF_SHADOW: bits 8..23 = the vertex' shadow request, relative to its range
+enum { RF_DEAD = 1, RF_WROTE = 2, RF_SHADOW = 4 };   // flags of RQ_B.z (RF_WROTE also in V_MAT bit 17); RF_SHADOW: bits 8..23 = the vertex' shadow request, relative to its group of four ranges
 // shadow request (compacted per range)
 // SQ_A = (o.xyz, d.x)  SQ_B = (d.yz, slot in range, add.x): 16-byte records; add.yz in two planes
 enum { SQ_A = 0, SQ_B = 4, S_ADDY = 8, S_ADDZ = 9, S_VIS = 10, S_PLANES = 11 };      // S_VIS: 1 once the walk found the request unoccluded
@@ -73,6 +73,8 @@ enum { G_WI = 0, G_PDF = 3, G_W = 4, G_WSUM = 5, G_M = 6, G_LID = 7, G_FLAG = 8,
 
 struct WfBuffers {
     Planes A, B, R, SQ;          // stride = cap
+    Planes Rn, SQn;              // packed pipeline: the ray / shadow requests of the NEXT bounce (the fused finish + shade kernel reads one set and
+                                 // writes the other; they alias planes 0..14 of A and 0..10 of B, which that pipeline never stores vertices in)
     Planes sampleLi;             // 3 planes, indexed by path id
     Planes stage;                // G_PLANES planes, indexed by path id
     Planes accum;                // 3 planes over pixel ordinals (Lframe carried across sample batches)
@@ -80,6 +82,14 @@ struct WfBuffers {
     int* cntS;                   // [depth][range] shadow requests
     int* grab;                   // [depth][2][8] range hand-out counters of the walk launches (zeroed per sample batch)
     int nRanges;
+    int pingpong;                // 1: frames whose finish and next shade are one kernel (the two request sets swap with every bounce)
+    // requests of bounce `depth` in R / SQ, those of the next one in Rn / SQn
+    HRT_D WfBuffers at_depth(int depth) const
+    {
+        WfBuffers w = *this;
+        if (pingpong && (depth & 1)) { w.R = Rn; w.SQ = SQn; w.Rn = R; w.SQn = SQ; }
+        return w;
+    }
 };
 
 struct WfGeom {
@@ -105,6 +115,111 @@ HRT_D int wave_prefix(bool keep, int& total)
     unsigned long long m = __ballot(keep);
     total = __popcll(m);
     return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+}
+
+// One vertex of the bounce loop (RTRay.cs:235-312): the bounce ray, the new throughput, the shadow request of a diffuse vertex and the
+// staged reservoir of a sample's first diffuse vertex.  Shared by the depth-0 shade (vertices from the G-buffer), the stand-alone shade
+// of the reference-layout pipeline (vertices from the V planes) and the fused finish + shade kernel (vertices straight from the winners).
+// pid: path id; index0: pixel index (FIRST only: else derived from pid); poison: `Li += T * 0` of a non-finite throughput (:286/:291).
+template <bool COUNT, bool FIRST>
+HRT_D void shade_vertex(const FrameK& k, const WfGeom& g, const DGBuffer& gb, const DReservoir& resPrev, long long nPix, const WfBuffers& W, int depth,
+                        F3 pos, F3 nrm, F3 alb, F3 I, int mat, float ior0, int pid, int index0,
+                        F3& T, Rng& rng, int& flg, Ray& ray, bool& wantShadow, F3& so, F3& sd, F3& sadd, bool& poison, F3& poisonAdd, Cnt<COUNT>& C)
+{
+    const int shade = mat & 0xFFFF;
+    flg = (mat >> 16) & RF_WROTE;
+    if (shade == HRT_SHADING_MIRROR)
+    {   // :235-244
+        F3 dirR = I - nrm * (2.f * dot(I, nrm));
+        ray = ray_with_normal_offset(pos, nrm, dirR);
+        T = T * alb;
+    }
+    else if (shade == HRT_SHADING_GLASS)
+    {   // :246-275
+        const float ior = ior0;
+        F3 Nuse = nrm;
+        bool outside = dot(I, nrm) < 0.f;
+        if (!outside) Nuse = Nuse * -1.f;
+        float iorUse = ior > 0.f ? ior : 1.5f;
+        float etaI = outside ? 1.f : iorUse;
+        float etaT = outside ? iorUse : 1.f;
+        F3 dirR = I - Nuse * (2.f * dot(I, Nuse));
+        float eta = etaI / etaT;
+        float cosIr = -dot(I, Nuse);
+        float kk = 1.f - eta * eta * (1.f - cosIr * cosIr);
+        bool refrOk = !(kk < 0.f);
+        F3 dirT = mk3(0.f, 0.f, 0.f);
+        if (refrOk) dirT = normalize(I * eta + Nuse * (eta * cosIr - hrt_sqrt(kk)));
+        float cosI = hrt_abs(dot(I, Nuse));
+        float r0 = (etaI - etaT) / (etaI + etaT);
+        r0 = r0 * r0;
+        float om = 1.f - cosI;
+        float om2 = om * om;
+        float Fr = r0 + (1.f - r0) * (om2 * om2 * om);
+        float xi = rng.next_f();
+        bool reflect = (!refrOk || xi < Fr);
+        ray = reflect ? ray_with_normal_offset(pos, Nuse, dirR) : ray_with_normal_offset(pos, -Nuse, dirT);
+        if (refrOk && xi >= Fr)
+        {
+            F3 tint = (alb.x == 0.f && alb.y == 0.f && alb.z == 0.f) ? mk3(1.f, 1.f, 1.f) : alb;
+            float etaScale = (etaI * etaI) / (etaT * etaT);
+            T = T * tint * etaScale;
+        }
+    }
+    else
+    {   // :277-317
+        int index = index0;
+        if (!FIRST)
+        {
+            int x, y;
+            ord_pixel(g, k, pid % g.nOrd, x, y);
+            index = y * k.width + x;
+        }
+        Frame fr = make_frame(nrm);
+        Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !(flg & RF_WROTE), pos, fr, alb, rng, C);
+        if (r.m > 0 && r.wSum > 0.f && r.w > 0.f)
+        {
+            F3 wiSel = r.wi;
+            int lidSel = r.lightId == 2 ? 2 : 1;
+            float nlSel = hrt_fmax(0.f, dot(nrm, wiSel));
+            if (nlSel > 0.f)
+            {
+                Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
+                float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
+                F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
+                F3 f_over_p = alb * LiSel * ((nlSel / pdfSel) * kINV_PI);
+                float Wt = r.wSum / (float)hrt_imax(1, r.m) / hrt_fmax(kEPS_MIN, r.w);
+                wantShadow = true;
+                so = sray.o; sd = sray.d;
+                sadd = T * (f_over_p * Wt);          // added to Li by wf_shadow iff unoccluded (:286/:291)
+            }
+        }
+        // The reference adds T * contrib also when contrib is (0, 0, 0) -- no light selected, or occluded (:286/:291).  That is a
+        // no-op (Li is never -0) unless a component of T is not finite (albedo products that overflowed): inf * 0 = NaN, and the
+        // component stays non-finite to the end of the sample, where SafeColor zeroes it, whatever else is added -- so it is
+        // poisoned here, before the visibility is known.  (T = 1 at a sample's first vertex.)
+        if (!FIRST && !(hrt_isfinite(T.x) && hrt_isfinite(T.y) && hrt_isfinite(T.z))) { poison = true; poisonAdd = T * mk3(0.f, 0.f, 0.f); }
+        if (!(flg & RF_WROTE))
+        {   // first diffuse vertex of this sample: stage the reservoir (resCur.Write :292-296)
+            W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, res_pdf(nrm, r));
+            W.stage.stf(G_W, pid, r.w); W.stage.stf(G_WSUM, pid, r.wSum); W.stage.sti(G_M, pid, r.m);
+            W.stage.sti(G_LID, pid, r.lightId); W.stage.sti(G_FLAG, pid, 1);
+            flg |= RF_WROTE;
+        }
+        F3 wi = sample_hemisphere_cosine(fr, rng);
+        ray = ray_with_normal_offset(pos, nrm, wi);
+        T = T * alb;
+        if (depth >= 3)
+        {   // :306-312
+            float maxC = hrt_fmax(T.x, hrt_fmax(T.y, T.z));
+            maxC = hrt_clamp(maxC, 0.05f, 0.98f);
+            if (rng.next_f() > maxC)
+            {   // throughput = 0; break  -> the path ends with its current Li (+ this vertex's direct light)
+                flg |= RF_DEAD;
+            }
+            else T = T * (1.0f / maxC);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ shade: vertex -> ray requests (RTRay.cs:235-312)
@@ -199,114 +314,25 @@ HRT_D void wf_shade_wave(const FrameK& k, const WfGeom& g, const DGBuffer& gb, c
                 rng.s = (uint32_t)V.ldi(V_RNG, slot);
                 mat = V.ldi(V_MAT, slot);
             }
-            const int shade = mat & 0xFFFF;
-            flg = (mat >> 16) & RF_WROTE;
-            if (shade == HRT_SHADING_MIRROR)
-            {   // :235-244
-                F3 dirR = I - nrm * (2.f * dot(I, nrm));
-                ray = ray_with_normal_offset(pos, nrm, dirR);
-                T = T * alb;
-            }
-            else if (shade == HRT_SHADING_GLASS)
-            {   // :246-275
-                const float ior = FIRST ? ior0 : V.ldf(V_IOR, slot);
-                F3 Nuse = nrm;
-                bool outside = dot(I, nrm) < 0.f;
-                if (!outside) Nuse = Nuse * -1.f;
-                float iorUse = ior > 0.f ? ior : 1.5f;
-                float etaI = outside ? 1.f : iorUse;
-                float etaT = outside ? iorUse : 1.f;
-                F3 dirR = I - Nuse * (2.f * dot(I, Nuse));
-                float eta = etaI / etaT;
-                float cosIr = -dot(I, Nuse);
-                float kk = 1.f - eta * eta * (1.f - cosIr * cosIr);
-                bool refrOk = !(kk < 0.f);
-                F3 dirT = mk3(0.f, 0.f, 0.f);
-                if (refrOk) dirT = normalize(I * eta + Nuse * (eta * cosIr - hrt_sqrt(kk)));
-                float cosI = hrt_abs(dot(I, Nuse));
-                float r0 = (etaI - etaT) / (etaI + etaT);
-                r0 = r0 * r0;
-                float om = 1.f - cosI;
-                float om2 = om * om;
-                float Fr = r0 + (1.f - r0) * (om2 * om2 * om);
-                float xi = rng.next_f();
-                bool reflect = (!refrOk || xi < Fr);
-                ray = reflect ? ray_with_normal_offset(pos, Nuse, dirR) : ray_with_normal_offset(pos, -Nuse, dirT);
-                if (refrOk && xi >= Fr)
-                {
-                    F3 tint = (alb.x == 0.f && alb.y == 0.f && alb.z == 0.f) ? mk3(1.f, 1.f, 1.f) : alb;
-                    float etaScale = (etaI * etaI) / (etaT * etaT);
-                    T = T * tint * etaScale;
-                }
-            }
-            else
-            {   // :277-317
-                int pid, index;
-                if (FIRST) { pid = pid0; index = index0; }
-                else
-                {
-                    pid = V.ldi(V_PID, slot);
-                    int x, y;
-                    ord_pixel(g, k, pid % g.nOrd, x, y);
-                    index = y * k.width + x;
-                }
-                Frame fr = make_frame(nrm);
-                Res r = restir_candidates<COUNT>(k, gb, resPrev, nPix, index, !(flg & RF_WROTE), pos, fr, alb, rng, C);
-                if (r.m > 0 && r.wSum > 0.f && r.w > 0.f)
-                {
-                    F3 wiSel = r.wi;
-                    int lidSel = r.lightId == 2 ? 2 : 1;
-                    float nlSel = hrt_fmax(0.f, dot(nrm, wiSel));
-                    if (nlSel > 0.f)
-                    {
-                        Ray sray = ray_with_normal_offset(pos, nrm, wiSel);
-                        float pdfSel = (lidSel == 2) ? hrt_fmax(kEPS_MIN, 1.f / 9.f) : hrt_fmax(kEPS_MIN, cos_hemi_pdf(nrm, wiSel) * (8.f / 9.f));
-                        F3 LiSel = (lidSel == 2) ? cv3(k.dirLightRadiance) : sky(k, wiSel);
-                        F3 f_over_p = alb * LiSel * ((nlSel / pdfSel) * kINV_PI);
-                        float Wt = r.wSum / (float)hrt_imax(1, r.m) / hrt_fmax(kEPS_MIN, r.w);
-                        wantShadow = true;
-                        so = sray.o; sd = sray.d;
-                        sadd = T * (f_over_p * Wt);          // added to Li by wf_shadow iff unoccluded (:286/:291)
-                    }
-                }
-                // The reference adds T * contrib also when contrib is (0, 0, 0) -- no light selected, or occluded (:286/:291).  That is a
-                // no-op (Li is never -0) unless a component of T is not finite (albedo products that overflowed): inf * 0 = NaN, and the
-                // component stays non-finite to the end of the sample, where SafeColor zeroes it, whatever else is added -- so it is
-                // poisoned here, before the visibility is known.  (T = 1 at a sample's first vertex.)
-                if (!FIRST && !(hrt_isfinite(T.x) && hrt_isfinite(T.y) && hrt_isfinite(T.z)))
-                    V.st3(V_LI, slot, V.ld3(V_LI, slot) + T * mk3(0.f, 0.f, 0.f));
-                if (!(flg & RF_WROTE))
-                {   // first diffuse vertex of this sample: stage the reservoir (resCur.Write :292-296)
-                    W.stage.st3(G_WI, pid, r.wi); W.stage.stf(G_PDF, pid, res_pdf(nrm, r));
-                    W.stage.stf(G_W, pid, r.w); W.stage.stf(G_WSUM, pid, r.wSum); W.stage.sti(G_M, pid, r.m);
-                    W.stage.sti(G_LID, pid, r.lightId); W.stage.sti(G_FLAG, pid, 1);
-                    flg |= RF_WROTE;
-                }
-                F3 wi = sample_hemisphere_cosine(fr, rng);
-                ray = ray_with_normal_offset(pos, nrm, wi);
-                T = T * alb;
-                if (depth >= 3)
-                {   // :306-312
-                    float maxC = hrt_fmax(T.x, hrt_fmax(T.y, T.z));
-                    maxC = hrt_clamp(maxC, 0.05f, 0.98f);
-                    if (rng.next_f() > maxC)
-                    {   // throughput = 0; break  -> the path ends with its current Li (+ this vertex's direct light)
-                        flg |= RF_DEAD;
-                    }
-                    else T = T * (1.0f / maxC);
-                }
-            }
+            bool poison = false; F3 poisonAdd = mk3(0.f, 0.f, 0.f);
+            int pidv = pid0;
+            if (!FIRST) { pidv = V.ldi(V_PID, slot); ior0 = V.ldf(V_IOR, slot); }
+            shade_vertex<COUNT, FIRST>(k, g, gb, resPrev, nPix, W, depth, pos, nrm, alb, I, mat, ior0, pidv, index0, T, rng, flg, ray, wantShadow, so, sd, sadd, poison, poisonAdd, C);
+            if (poison) V.st3(V_LI, slot, V.ld3(V_LI, slot) + poisonAdd);
         }
         int total;
         int off = wave_prefix(wantShadow, total);
         if (wantShadow)
         {
+            // the request lives in the SHADING wave's own range; vertex and request refer to each other relative to the 4-range group
+            // (the fused finish + shade kernel writes a vertex into another range of its group than the one its wave owns)
+            const long long groupBase = (long long)(range & ~3) * kRange;
             long long q = base + sqCount + off;
             W.SQ.st4(SQ_A, q, mkq(so.x, so.y, so.z, sd.x));
-            W.SQ.st4(SQ_B, q, mkq(sd.y, sd.z, __int_as_float((int)(slot - base)), sadd.x));
+            W.SQ.st4(SQ_B, q, mkq(sd.y, sd.z, __int_as_float((int)(slot - groupBase)), sadd.x));
             W.SQ.stf(S_ADDY, q, sadd.y); W.SQ.stf(S_ADDZ, q, sadd.z);
             W.SQ.sti(S_VIS, q, 0);
-            flg |= RF_SHADOW | ((sqCount + off) << 8);        // wf_finish adds the direct light if the walk leaves S_VIS set
+            flg |= RF_SHADOW | ((int)(q - groupBase) << 8);        // wf_finish adds the direct light if the walk leaves S_VIS set
         }
         if (FIRST && valid && !(flg & RF_WROTE)) W.stage.sti(G_FLAG, s_first_pid[(range & 3) * kRange + i], 0);     // no reservoir from this sample yet
         if (valid)
@@ -337,7 +363,7 @@ HRT_D void wf_shadow_wave(const TR& tr, const WfBuffers& W, const Planes& V, int
             Ray r; r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = inv_dir(r.d);
             if (!tr.template occluded<COUNT>(r, 1e29f, C))
             {
-                const long long slot = base + __float_as_int(qb.z);
+                const long long slot = (long long)(range & ~3) * kRange + __float_as_int(qb.z);
                 V.st3(V_LI, slot, V.ld3(V_LI, slot) + mk3(qb.w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q)));
             }
         }
@@ -516,7 +542,7 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
             Li = V.ld3(V_LI, slot);
             if (flg & RF_SHADOW)
             {   // direct light of this vertex, if its shadow walk found the light unoccluded (:286/:291)
-                const long long q = base + ((flg >> 8) & 0xFFFF);
+                const long long q = (long long)(range & ~3) * kRange + ((flg >> 8) & 0xFFFF);
                 if (W.SQ.ldi(S_VIS, q)) Li = Li + mk3(W.SQ.ld4(SQ_B, q).w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q));
             }
             if (!dead)
@@ -559,6 +585,161 @@ HRT_D void wf_finish_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const 
     }
     // range j of the group now holds survivors [256 j, 256 j + 256) of the group
     if (lane == 0) W.cntA[(depth + 1) * W.nRanges + range] = max(0, min(kRange, groupTotal - (range - groupRange) * kRange));
+}
+
+// finish of bounce `depth` FUSED with the shade of bounce depth + 1 (packed layout, every bounce but the last): the winner's shading
+// feeds the next vertex in registers -- position, normal, albedo, incoming direction, throughput, RNG and material never round-trip
+// through the 22 vertex planes (88 B written and read back per surviving path and bounce before); only Li and the path id are kept
+// for the finish that follows.  Same arithmetic in the same order as wf_finish_wave + wf_shade_wave, so the same bits.
+template <int FEAT, bool COUNT>
+HRT_D void wf_finish_shade_wave(const TracerPackedT<FEAT>& tr, const FrameK& k, const WfGeom& g, const DGBuffer& gb, const DReservoir& resPrev, long long nPix,
+                                const WfBuffers& W, const Planes& V, const Planes& Vn, int depth, int range, Cnt<COUNT>& C)
+{
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long base = (long long)range * kRange;
+    const int n = range >= 0 ? W.cntA[depth * W.nRanges + range] : 0;
+    int mine = 0;
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int i = it * 64 + lane;
+        bool sv = false;
+        if (i < n)
+        {
+            const float4 qb = W.R.ld4(RQ_B, base + i);
+            if (!(__float_as_int(qb.z) & RF_DEAD)) sv = W.R.ld4(RQ_H, base + i).x < 1e29f;
+        }
+        mine += __popcll(__ballot(sv));
+    }
+    if (lane == 0) s_cnt[wv] = mine;
+    __syncthreads();
+    int before = 0, groupTotal = 0;
+    for (int j = 0; j < 4; j++) { const int cj = s_cnt[j]; if (j < wv) before += cj; groupTotal += cj; }
+    if (range < 0) return;
+    const int groupRange = range & ~3;
+    const long long groupBase = (long long)groupRange * kRange;
+    int outCount = before, sqCount = 0;
+    // The winners are shaded 64 source entries at a time (dependent random fetches: instance, triangle, material records), but only
+    // the survivors go on to the expensive half (eight ReSTIR candidates per diffuse vertex): they wait in a wave-local LDS list until
+    // 64 of them fill a wave, so that half runs with full lanes whatever the survival rate.  An entry is what the fetches produced
+    // (normal, albedo, material word, ior, hit distance), the radiance so far and the source slot; ray, throughput, RNG state and path
+    // id are read again from the source slot.  The requests of bounce depth + 1 go to the OTHER set (Rn / SQn): other waves of the
+    // group may still be reading this wave's range as bounce `depth`.
+    constexpr int kPend = 128;
+    __shared__ float s_pend[4][13][kPend];
+    float (*pend)[kPend] = s_pend[wv];
+    int nPend = 0;
+    auto shade_batch = [&](int cnt) {        // the first cnt <= 64 entries of the list become vertices of bounce depth + 1
+        const bool act = lane < cnt;
+        bool wantShadow = false;
+        F3 Li = mk3(0.f, 0.f, 0.f), T = Li, so = Li, sd = Li, sadd = Li;
+        Rng rng; rng.s = 0;
+        int flgNext = 0, pid = 0;
+        Ray ray; ray.o = Li; ray.d = Li;
+        if (act)
+        {
+            const long long slot = base + __float_as_int(pend[0][lane]);
+            const F3 nrm = mk3(pend[1][lane], pend[2][lane], pend[3][lane]), alb = mk3(pend[4][lane], pend[5][lane], pend[6][lane]);
+            const int mat = __float_as_int(pend[7][lane]);
+            const float ior = pend[8][lane], ht = pend[9][lane];
+            Li = mk3(pend[10][lane], pend[11][lane], pend[12][lane]);
+            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
+            const F3 ro = mk3(qa.x, qa.y, qa.z), rd = mk3(qa.w, qb.x, qb.y);
+            pid = V.ldi(V_PID, slot);
+            T = W.R.ld3(R_T, slot);
+            rng.s = (uint32_t)__float_as_int(qb.w);
+            bool poison = false; F3 poisonAdd = mk3(0.f, 0.f, 0.f);
+            shade_vertex<COUNT, false>(k, g, gb, resPrev, nPix, W, depth + 1, ro + rd * ht, nrm, alb, rd, mat, ior, pid, 0, T, rng, flgNext, ray, wantShadow, so, sd, sadd, poison, poisonAdd, C);
+            if (poison) Li = Li + poisonAdd;
+        }
+        int totalS;
+        const int offS = wave_prefix(wantShadow, totalS);
+        if (act)
+        {
+            const long long o = groupBase + outCount + lane;
+            if (wantShadow)
+            {
+                const long long q = base + sqCount + offS;
+                W.SQn.st4(SQ_A, q, mkq(so.x, so.y, so.z, sd.x));
+                W.SQn.st4(SQ_B, q, mkq(sd.y, sd.z, __int_as_float((int)(o - groupBase)), sadd.x));
+                W.SQn.stf(S_ADDY, q, sadd.y); W.SQn.stf(S_ADDZ, q, sadd.z);
+                W.SQn.sti(S_VIS, q, 0);
+                flgNext |= RF_SHADOW | ((int)(q - groupBase) << 8);
+            }
+            Vn.st3(V_LI, o, Li);
+            Vn.sti(V_PID, o, pid);
+            W.Rn.st4(RQ_A, o, mkq(ray.o.x, ray.o.y, ray.o.z, ray.d.x));
+            W.Rn.st4(RQ_B, o, mkq(ray.d.y, ray.d.z, __int_as_float(flgNext), __int_as_float((int)rng.s)));
+            W.Rn.st3(R_T, o, T);
+        }
+        outCount += cnt;
+        sqCount += totalS;
+        // what is left moves to the front of the list
+        __builtin_amdgcn_wave_barrier();
+        float keep[13];
+        const bool mv = lane + cnt < nPend;
+        if (mv) for (int c = 0; c < 13; c++) keep[c] = pend[c][lane + cnt];
+        __builtin_amdgcn_wave_barrier();
+        if (mv) for (int c = 0; c < 13; c++) pend[c][lane] = keep[c];
+        __builtin_amdgcn_wave_barrier();
+        nPend -= cnt;
+    };
+    for (int it = 0; it * 64 < n; it++)
+    {
+        const int i = it * 64 + lane;
+        const long long slot = base + i;
+        bool survive = false;
+        Hit h;
+        F3 Li = mk3(0.f, 0.f, 0.f);
+        int matNext = 0;
+        if (i < n)
+        {
+            const float4 qa = W.R.ld4(RQ_A, slot), qb = W.R.ld4(RQ_B, slot);
+            const int flg = __float_as_int(qb.z);
+            const bool dead = (flg & RF_DEAD) != 0;
+            bool missed = false;
+            Ray r; r.o = mk3(qa.x, qa.y, qa.z); r.d = mk3(qa.w, qb.x, qb.y); r.inv = mk3(0.f, 0.f, 0.f);
+            Li = V.ld3(V_LI, slot);
+            if (flg & RF_SHADOW)
+            {
+                const long long q = groupBase + ((flg >> 8) & 0xFFFF);
+                if (W.SQ.ldi(S_VIS, q)) Li = Li + mk3(W.SQ.ld4(SQ_B, q).w, W.SQ.ldf(S_ADDY, q), W.SQ.ldf(S_ADDZ, q));
+            }
+            if (!dead)
+            {
+                const float4 qh = W.R.ld4(RQ_H, slot);
+                const float ht = qh.x;
+                if (!(ht < 1e29f)) missed = true;
+                else { survive = true; tr.finish_hit(r, ht, qh.y, __float_as_int(qh.z), __float_as_int(qh.w), h); matNext = (h.shade & 0xFFFF) | ((flg & RF_WROTE) << 16); }
+            }
+            if (!survive)
+            {
+                if (missed) Li = Li + W.R.ld3(R_T, slot) * sky(k, r.d);
+                W.sampleLi.st3(0, V.ldi(V_PID, slot), Li);
+            }
+        }
+        int total;
+        const int off = wave_prefix(survive, total);
+        if (survive)
+        {
+            const int e = nPend + off;
+            const F3 nn = normalize(h.n);
+            pend[0][e] = __int_as_float(i);
+            pend[1][e] = nn.x; pend[2][e] = nn.y; pend[3][e] = nn.z;
+            pend[4][e] = h.albedo.x; pend[5][e] = h.albedo.y; pend[6][e] = h.albedo.z;
+            pend[7][e] = __int_as_float(matNext); pend[8][e] = h.ior; pend[9][e] = h.t;
+            pend[10][e] = Li.x; pend[11][e] = Li.y; pend[12][e] = Li.z;
+        }
+        nPend += total;
+        __builtin_amdgcn_wave_barrier();
+        if (nPend >= 64) shade_batch(64);
+    }
+    if (nPend > 0) shade_batch(nPend);
+    if (lane == 0)
+    {
+        W.cntA[(depth + 1) * W.nRanges + range] = max(0, min(kRange, groupTotal - (range - groupRange) * kRange));
+        W.cntS[(depth + 1) * W.nRanges + range] = sqCount;
+    }
 }
 
 // ------------------------------------------------------------------ resolve: ordered sample sum, reservoir hand-off, framebuffer store (:320-324)
