@@ -52,7 +52,7 @@ HRT_HD float    hrt_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
  * instruction.  The two rules differ only when an operand is NaN (call sites in kernel code: IntersectAABB
  * Engine/SceneDeviceViews.cs:500-513, SafeColor Engine/RTRay.cs:651-653, the clamps of the samplers and of ReSTIR).
  * Decision: kernels and oracle evaluate the minNum rule (hrt_fmin / hrt_fmax below); -DHRT_KERNEL_MINMAX_DOTNET builds the
- * oracle with the CPUAccelerator rule instead (oracle/liborc_dotnet.so), and tests/test_minmax_rule.py renders the golden
+ * oracle with the CPUAccelerator rule instead (the `dotnet` variant of the checker under oracle/), and tests/test_minmax_rule.py renders the golden
  * fixtures and the strips of BASELINE configs 3 / 4 / 5 under both and requires byte-equal outputs: no NaN reaches a min / max on
  * any BASELINE frame, so the choice is immaterial there.  It is NOT immaterial on hostile inputs (NaN centres, lights, transforms:
  * the same test counts the hostile frames that differ); there "identical to the oracle" means identical under the minNum rule. */
