@@ -14,6 +14,8 @@ ap.add_argument("--small", action="store_true", help="960x540 instead of the con
 ap.add_argument("--limits", default="", help="bytes,minNodes,minBlasNodes of the treelet cut (default: the shipped values)")
 ap.add_argument("--nocheck", action="store_true")
 ap.add_argument("--only", default="", help="plain | treelets: run one side only (profiling)")
+ap.add_argument("--save", default="", help="with --only: write this side's output arrays to <file>.cfgN.npz")
+ap.add_argument("--compare", default="", help="with --only: compare this side's output arrays with <file>.cfgN.npz (another process / build / environment)")
 args = ap.parse_args()
 spp = dict((int(a), int(b)) for a, b in (x.split(":") for x in args.spp.split(",")))
 lim = [int(v) for v in args.limits.split(",")] if args.limits else None
@@ -39,6 +41,13 @@ for cid in [int(c) for c in args.configs.split(",")]:
         st = r.synchronize()
         res[label] = (out, st.kernel_ms[0] / st.frames, st.kernel_ms[1] / st.frames)
         print("cfg%d %dx%d spp%d %-8s primary %.3f ms  path stage %.3f ms" % (cid, p.width, p.height, p.spp, label, res[label][1], res[label][2]), flush=True)
+    if args.only and (args.save or args.compare):
+        mine = res[args.only][0]
+        if args.save: np.savez(args.save + ".cfg%d.npz" % cid, **mine)
+        if args.compare:
+            other = np.load(args.compare + ".cfg%d.npz" % cid)
+            bad = [k for k in mine if np.ascontiguousarray(mine[k]).tobytes() != np.ascontiguousarray(other[k]).tobytes()]
+            print("   %s vs %s: %s" % (args.only, args.compare, "IDENTICAL" if not bad else "MISMATCH %s" % bad), flush=True)
     if not args.nocheck and not args.only:
         a, b = res["plain"][0], res["treelets"][0]
         bad = {}
