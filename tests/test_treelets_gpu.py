@@ -96,3 +96,55 @@ def test_baseline_meshes_full_size(renderer, cfg_id, spp):
         renderer.render_params(p, o, flags=fl)
         out[label] = a
     H.assert_outputs_equal(out["plain"], out["treelets"])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("hostile", [False, True])
+def test_random_mesh_scenes_through_the_treelet_walker(orc, hooks_renderer, low_limits, hostile):
+    """The differential fuzz of tests/test_fuzz_gpu.py (random sphere sets, 1-3 textured / alpha-cut / transformed meshes, random camera,
+    lights, spp, depth 0..7, reuse over two frames; `hostile`: NaN / infinite / degenerate values planted) with treelets of a few nodes:
+    every array of every frame against the oracle."""
+    from tests import test_fuzz_gpu as FZ
+    low_limits.hrt_debug_set_treelet_limits(400, 3, 7)
+    r = hooks_renderer
+    failures, with_treelets, case = [], 0, 0
+    while with_treelets < 24 and case < 400:
+        seed = 0x7E1E7 + case + (0x700000 if hostile else 0)
+        case += 1
+        ops, fr = FZ._scene_recipe(seed)
+        if not any(op[0] == "mesh" for op in ops):
+            continue
+        if hostile:
+            ops, fr = FZ._poison(ops, fr, seed)
+        so = orc.OrcScene(); FZ._apply(so, ops)
+        s = engine.Scene(); FZ._apply(s, ops)
+        r.commit(s)
+        if low_limits.hrt_debug_treelet_count(r._ctx) == 0:
+            continue
+        with_treelets += 1
+        cfg = scenes.Config("fz", fr["w"], fr["h"], fr["spp"], fr["origin"], fr["lookat"], max_depth=fr["max_depth"], vfov=fr["vfov"],
+                            extra={"sun_azimuth": fr["sun"][0], "sun_elevation": fr["sun"][1]})
+        w, h = fr["w"], fr["h"]
+        r.reset_history()
+        A, B = H.new_reservoirs(w, h), H.new_reservoirs(w, h)
+        for f in range(2 if fr["reuse"] else 1):
+            frame = fr["frame"] + f
+            po_ = scenes.frame_params(cfg, *H.host_funcs("orc", orc), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+            pg_ = scenes.frame_params(cfg, *H.host_funcs("hrt"), frame=frame, reuse=fr["reuse"], rng_lock_noise=fr["lock"])
+            prev, cur = (B, A) if (frame & 1) == 0 else (A, B)
+            ref, oo = T.alloc_outputs(w, h)
+            for k, a in cur.items():
+                ref[k] = a; setattr(oo, k, a.ctypes.data)
+            po = T.Outputs()
+            for k, a in prev.items():
+                setattr(po, k, a.ctypes.data)
+            orc.render_frame(so.desc(), po_, oo, po)
+            got, og = T.alloc_outputs(w, h)
+            r.render_params(pg_, og, flags=T.FLAG_STREAMED | T.FLAG_TREELETS)
+            bad = {k: int(np.count_nonzero(~H.bits_equal(ref[k], got[k]))) for k in ref}
+            bad = {k: v for k, v in bad.items() if v}
+            if bad:
+                failures.append((seed, f, bad))
+                break
+    assert with_treelets >= 12, "too few random scenes got treelets (%d)" % with_treelets
+    assert not failures, "cases that differ from the oracle (seed, frame, {array: elements}): %s" % failures
