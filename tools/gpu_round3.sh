@@ -24,6 +24,15 @@ if [ "$WHAT" = all ] || [ "$WHAT" = tiles ]; then
   timeout -k 10 300 python tools/tile_projection.py --config 3 --frames 4 --out $OUT/tile_scaling_config3.json > $OUT/tiles3.log 2>&1; echo "tiles3 rc=$?"; tail -2 $OUT/tiles3.log
   timeout -k 10 600 python tools/tile_projection.py --config 4 --frames 1 --out $OUT/tile_scaling_config4.json > $OUT/tiles4.log 2>&1; echo "tiles4 rc=$?"; tail -6 $OUT/tiles4.log
 fi
+if [ "$WHAT" = all ] || [ "$WHAT" = profiles ]; then
+  for spec in "2:0" "3:0" "4:4"; do
+    c=${spec%%:*}; spp=${spec#*:}; SPP=""; [ "$spp" != 0 ] && SPP="--spp $spp"
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c$c -- python bench.py --config $c $SPP --steps 20 --warmup 5 --cpu-seconds 0 --pmc off --extras 0 > $OUT/prof_bench_c$c.json 2> $OUT/prof_c$c.err; echo "rocprof config $c rc=$?"
+    python tools/kstats.py $OUT/prof_c$c 12
+    cp $(find $OUT/prof_c$c -name "*kernel_stats.csv" | head -1) $OUT/config${c}_kernel_stats.csv
+    find $OUT/prof_c$c -name "*.csv" -delete; find $OUT/prof_c$c -name "*.db" -delete
+  done
+fi
 if [ "$WHAT" = all ] || [ "$WHAT" = rehearsal ]; then
   HRT_BENCH_REHEARSAL=1 timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 > $OUT/bench_rehearsal2.json 2> $OUT/bench_rehearsal2.err; echo "rehearsal rc=$?"
   python - <<PY
