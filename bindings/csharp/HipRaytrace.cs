@@ -42,7 +42,8 @@ namespace ILGPU_Raytracing.Engine
     public enum HrtFlags : uint
     {
         None = 0, Counters = 1, SkipPrimary = 2, ReferenceLayout = 4, NoSync = 8, Megakernel = 16, Streamed = 32,
-        PrimaryOnly = 64, Exchanged = 128
+        PrimaryOnly = 64, Exchanged = 128,
+        Treelets = 256      // opt-in LDS-staged treelet walker: same pictures, slower than the default (DESIGN.md 5.4)
     }
 
     [StructLayout(LayoutKind.Sequential)]
