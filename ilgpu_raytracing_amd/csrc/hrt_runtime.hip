@@ -1131,7 +1131,7 @@ constexpr long long kSmallSceneNodes = 256;
 constexpr long long kWfMaxPaths = 1ll << 25;      // paths resident per sample batch (320 B of workspace each)
 
 // workspace of batch lane `lane` (0 / 1); growing one drains the device first (frames of earlier calls may still use it)
-int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nOrd, int nRanges, int maxDepth, WfBuffers& W)
+int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nOrd, int nRanges, int maxDepth, WfBuffers& W, bool treelets = false)
 {
     const size_t planes = 2 * V_PLANES + R_PLANES + S_PLANES + 3 + G_PLANES;
     const size_t bytes = (size_t)planes * (size_t)cap * sizeof(float);
@@ -1157,8 +1157,8 @@ int ensure_workspace(hrt_ctx* c, DeviceState& d, int lane, long long cap, int nO
         HIPCHK(c, hipMalloc(&v, (size_t)3 * (size_t)nOrd * sizeof(float)));
         d.wf_accum = (float*)v; d.wf_accum_floats = (size_t)3 * (size_t)nOrd;
     }
-    if (d.tl_ok)
-    {   // queues of the treelet walker: per walk kind key / state / binned indices over the path slots, and the per-treelet counters
+    if (d.tl_ok && treelets)
+    {   // queues of the treelet walker (only for frames that ask for it: HRT_FLAG_TREELETS): per walk kind key / state / binned indices over the path slots, and the per-treelet counters
         const size_t nTl = (size_t)d.dtl.nTl;
         const size_t ints = ((nTl + 32 + nTl + 1 + nTl) + 63) & ~(size_t)63;
         const size_t per0 = (size_t)cap * (4 + 16 + 4) + ints * 4, per1 = (size_t)cap * (4 + 32 + 4) + ints * 4;
@@ -1309,7 +1309,7 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     const int nRanges = (int)((batchPaths + kRange - 1) / kRange);
     const long long cap = (long long)nRanges * kRange;
     WfBuffers Wl[kMaxLanes];
-    for (int j = 0; j < nLanes; j++) { int rc = ensure_workspace(c, d, j, cap, g.nOrd, nRanges, k.maxDepth, Wl[j]); if (rc != HRT_OK) return rc; }
+    for (int j = 0; j < nLanes; j++) { int rc = ensure_workspace(c, d, j, cap, g.nOrd, nRanges, k.maxDepth, Wl[j], treelets); if (rc != HRT_OK) return rc; }
     hipStream_t laneMain[kMaxLanes], laneSide[kMaxLanes];
     laneMain[0] = d.stream; laneSide[0] = d.stream2;
     for (int j = 1; j < kMaxLanes; j++) { laneMain[j] = d.laneStream[j][0]; laneSide[j] = d.laneStream[j][1]; }
