@@ -36,7 +36,6 @@ constexpr int kTlSpanMin = 512;            // rays per workgroup span of a round
 // [7] idle lanes summed over iterations [8..12] shader-clock cycles in refill / node steps / instance + leaf steps / retire / staging [13] waves [14] LDS node-step rounds [15] global rounds
 #ifdef HRT_TL_STATS
 __device__ unsigned long long g_tl_stats[8][2][16];      // [0] PHASE 0, [1..6] rounds of PHASE 1, [7] PHASE 2
-__device__ int g_tl_stat_slot_dummy;
 #define TSTAT(i, v) ts[i] += (unsigned long long)(v)
 #define TTIME(i) { const long long tnow_ = (long long)__builtin_readcyclecounter(); ts[i] += (unsigned long long)(tnow_ - tt_); tt_ = tnow_; }
 #else
