@@ -1489,7 +1489,14 @@ int run_path_stage(hrt_ctx* c, DeviceState& d, const TR& tr, const FrameK& k, co
     return HRT_OK;
 }
 
-int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce);       // defined with the scene-update code below
+struct SahTopology { std::vector<int32_t> order; std::vector<NodeQ> nodes; std::vector<int> parent, nchild; int leaves = 0; };
+void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out);
+constexpr int64_t kAnyTreeMinInstances = 256;       // scenes of fewer instances keep the uploaded tree alone (second tree: see build_second_tree)
+#ifndef HRT_SAH_MAX_LOG2            // A/B (300 001 instances: LBVH topology 12.3 ms per frame and 0.29 s per upload, SAH 11.5 ms and 0.38 s)
+#define HRT_SAH_MAX_LOG2 21
+#endif
+constexpr int64_t kHostSahMaxInstances = (int64_t)1 << HRT_SAH_MAX_LOG2;
+int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce, const SahTopology* pre = nullptr, const hrt_instance* hostInst = nullptr);       // defined with the scene-update code below
 
 } // namespace
 
@@ -1679,6 +1686,19 @@ try {
     const int64_t capTI = std::max<int64_t>(std::max<int64_t>(s->n_tlasInstanceIndices, s->n_instances), 1);
     hrt_bvh_node emptyTlas; std::memset(&emptyTlas, 0, sizeof(emptyTlas));
     emptyTlas.left = emptyTlas.right = emptyTlas.first = emptyTlas.skipIndex = -1;   // an empty TLAS ends the walk at once
+    // topology of the second tree (many-sphere scenes): a function of the instances alone, computed once for all devices
+    SahTopology sahOnce; bool haveSah = false;
+#ifndef HRT_NO_HOST_SAH
+#ifndef HRT_NO_ANY_TREE
+    if (ph.ok && ph.feat == 0 && s->n_instances >= kAnyTreeMinInstances && ph.n_tlasX > 0 && ph.inst_once && s->n_tlasInstanceIndices == s->n_instances &&
+        ph.own_in_world && s->n_instances <= kHostSahMaxInstances && s->n_instances > 2)
+    {
+        const std::vector<hrt_instance> inst(s->instances, s->instances + s->n_instances);
+        host_sah_topology(inst, sahOnce);
+        haveSah = true;
+    }
+#endif
+#endif
     TreeletsHost tlh;
     if (ph.ok && (ph.feat & 1) && ph.blas_refit_ok && !ph.meshRanges.empty()) build_treelets(ph.blas, ph.bsubend, ph.meshRanges, g_treelet_limits, tlh);
     for (DeviceState& d : c->dev)
@@ -1798,7 +1818,7 @@ try {
             d.tl_ok = tl_shared_bytes(d.dtl.tlBytesMax, d.dtl.redLds, histBins) <= (size_t)d.max_lds;
         }
         HIPCHK(c, hipStreamSynchronize(d.stream));      // host arrays are only borrowed for the duration of the call
-        if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once))
+        if (int rcB = build_second_tree(c, d, s->tlasInstanceIndices, s->n_tlasInstanceIndices, ph.inst_once, haveSah ? &sahOnce : nullptr, s->instances))
         {   // the second tree is an accelerator, not part of the scene: without memory for it the walks use the uploaded tree
             if (rcB != HRT_ERR_OUT_OF_MEMORY) return rcB;
             (void)hipGetLastError();
@@ -1846,7 +1866,6 @@ int ensure_lbvh_scratch(hrt_ctx* c, DeviceState& d)
 // reference's median split cuts such a scene into slabs when one instance dominates the bounds (the ground sphere of BASELINE
 // config 3: 103 node visits per ray against 50).  Needs the uploaded tree to list every instance exactly once (the
 // second tree is built over "the instances").  Scene updates refit it (refit_second_tree).
-constexpr int64_t kAnyTreeMinInstances = 256;
 
 // Topology of the second tree built on the HOST with a binned surface-area heuristic (16 bins on each axis over the box centres of
 // the range, the split of least area(left) * n(left) + area(right) * n(right); leaves of at most four instances; a range the bins cannot
@@ -1855,12 +1874,7 @@ constexpr int64_t kAnyTreeMinInstances = 256;
 // device's (tlas_finish, tlas_inflate), exactly as for the LBVH the scene updates build.  Against that LBVH: 6-10 % fewer node
 // visits per ray on config 3 (tools/tree_order_model.py); the scene updates keep the LBVH, which is built in 0.3 ms, and so do
 // scenes of more than two million instances.
-#ifndef HRT_SAH_MAX_LOG2            // A/B (300 001 instances: LBVH topology 12.3 ms per frame and 0.29 s per upload, SAH 11.5 ms and 0.38 s)
-#define HRT_SAH_MAX_LOG2 21
-#endif
-constexpr int64_t kHostSahMaxInstances = (int64_t)1 << HRT_SAH_MAX_LOG2;
 constexpr int kSahLeaf = 4;       // instances per leaf at most (config 3, path stage + launch 1: 15.66 / 15.37 / 15.39 / 15.41 ms for 2 / 3 / 4 / 6)
-struct SahTopology { std::vector<int32_t> order; std::vector<NodeQ> nodes; std::vector<int> parent, nchild; int leaves = 0; };
 void host_sah_topology(const std::vector<hrt_instance>& inst, SahTopology& out)
 {
     const int n = (int)inst.size();
@@ -2023,7 +2037,7 @@ bool reorder_second_tree(const std::vector<NodeQ>& X, const int sign[3], int bas
     }
     return placed == nX;
 }
-int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce)
+int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, int64_t nSlots, bool instOnce, const SahTopology* pre, const hrt_instance* hostInst)
 {
     d.any_ok = false; d.any_built = false;
 #ifdef HRT_NO_ANY_TREE             // A/B
@@ -2049,13 +2063,21 @@ int build_second_tree(hrt_ctx* c, DeviceState& d, const int32_t* uploadedSlots, 
     T.scanIn = (unsigned long long*)d.tl2mem[9]; T.scanOut = (unsigned long long*)d.tl2mem[10]; T.sa = (float*)d.tl2mem[11]; T.saBase = (float*)d.tl2mem[12];
     T.flags = (int*)d.tl2mem[13]; T.cost = (float*)((char*)d.tl2mem[13] + 16);
     int leaves = 0;
-    std::vector<hrt_instance> inst((size_t)c->n_inst);
-    HIPCHK(c, hipMemcpy(inst.data(), T.instances, inst.size() * sizeof(hrt_instance), hipMemcpyDeviceToHost));
+    // the instances as the host uploaded them (no copy back from the device when the caller still has them)
+    std::vector<hrt_instance> inst;
+    if (hostInst) inst.assign(hostInst, hostInst + c->n_inst);
+    else
+    {
+        inst.resize((size_t)c->n_inst);
+        HIPCHK(c, hipMemcpy(inst.data(), T.instances, inst.size() * sizeof(hrt_instance), hipMemcpyDeviceToHost));
+    }
 #ifndef HRT_NO_HOST_SAH            // A/B
     if (c->n_inst <= kHostSahMaxInstances && c->n_inst > 2)
     {
-        SahTopology sah;
-        host_sah_topology(inst, sah);
+        // the topology depends on the instances alone: the upload computes it once and hands it to every device
+        SahTopology own;
+        if (!pre) host_sah_topology(inst, own);
+        const SahTopology& sah = pre ? *pre : own;
         T.nT = (int)sah.nodes.size(); T.nTI = (int)c->n_inst; leaves = sah.leaves;
         if (T.nT > T.capT || T.nTI > T.capTI || T.nT != 2 * leaves - 1) return fail(c, HRT_ERR_HIP, "second tree: host topology does not fit");
         HIPCHK(c, hipMemcpyAsync(T.tlas, sah.nodes.data(), sah.nodes.size() * sizeof(NodeQ), hipMemcpyHostToDevice, d.stream));
