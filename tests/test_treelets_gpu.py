@@ -148,3 +148,27 @@ def test_random_mesh_scenes_through_the_treelet_walker(orc, hooks_renderer, low_
                 break
     assert with_treelets >= 12, "too few random scenes got treelets (%d)" % with_treelets
     assert not failures, "cases that differ from the oracle (seed, frame, {array: elements}): %s" % failures
+
+
+def test_treelets_survive_instance_moves(hooks_renderer, low_limits):
+    """hrt_scene_update_instances regenerates the leaf-slot records and may rebuild the TLAS; the treelets hang on the BLAS roots and stay
+    valid: after a move, a TLAS refit and a TLAS rebuild the treelet walker still renders what the plain walker renders."""
+    cfg, w, h, spp = scenes.CONFIGS[4], 192, 108, 2
+    low_limits.hrt_debug_set_treelet_limits(2048, 7, 32)
+    r = hooks_renderer
+    s = engine.Scene(); scenes.build_config4(s, 48, 48); r.commit(s)
+    n_tl = low_limits.hrt_debug_treelet_count(r._ctx)
+    assert n_tl > 0
+    mesh = [i for i, rec in enumerate(s.arrays()["instances"]) if rec["type"] == 2][0]
+    p = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+    for policy, xf in ((T.REBUILD_FORCE_REFIT, scenes.rotation_affine("y", 0.0, 1.0, (0.2, 0.05, -0.1))),
+                       (T.REBUILD_FORCE_REBUILD, scenes.rotation_affine("y", 25.0, 0.8, (-0.1, 0.1, 0.2)))):
+        r.update_instances([mesh], [xf], policy)
+        assert low_limits.hrt_debug_treelet_count(r._ctx) == n_tl
+        out = {}
+        for label, fl in (("plain", T.FLAG_STREAMED), ("treelets", T.FLAG_STREAMED | T.FLAG_TREELETS)):
+            r.reset_history()
+            a, o = T.alloc_outputs(w, h)
+            r.render_params(p, o, flags=fl)
+            out[label] = a
+        H.assert_outputs_equal(out["plain"], out["treelets"])
