@@ -244,7 +244,8 @@ def is_counting_kernel(name):
 def pmc_for(cfg_id, spp, allow_run, out_dir, strips=None, allow_file=True):
     """(per-launch counter sums of the path-trace stage, source description).  Measured now if allowed, else the committed file."""
     src = None
-    res = measure_pmc(cfg_id, spp, out_dir, strips=strips) if allow_run else None
+    # N > 1: the other ranks wait for rank 0 in init_process_group meanwhile -- bound the passes well below its time-out
+    res = measure_pmc(cfg_id, spp, out_dir, strips=strips, timeout_s=60 if strips else 240) if allow_run else None
     if res is not None:
         src = {"kind": "measured in this run", "how": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*, GRBM_GUI_ACTIVE | SQ_INSTS_VALU_TRANS_F32) + --kernel-trace over `bench.py --pmc-child --config %d`%s%s"
                       % (cfg_id, " --spp %d" % spp if spp else "", " --pmc-strips %d,%d" % strips if strips else ""),
