@@ -172,3 +172,23 @@ def test_treelets_survive_instance_moves(hooks_renderer, low_limits):
             r.render_params(p, o, flags=fl)
             out[label] = a
         H.assert_outputs_equal(out["plain"], out["treelets"])
+
+
+def test_treelets_on_a_context_of_two_device_slots(hooks_lib, low_limits):
+    """One context over two device slots (both on the one GPU: every slot keeps its own treelets and queues): the interleaved strips of the
+    treelet walker's frame are the plain walker's."""
+    cfg, w, h, spp = scenes.CONFIGS[4], 192, 112, 2
+    low_limits.hrt_debug_set_treelet_limits(2048, 7, 32)
+    r = engine.RTRenderer([0, 0], library=hooks_lib)
+    try:
+        s = engine.Scene(); scenes.build_config4(s, 48, 48); r.commit(s)
+        p = scenes.frame_params(cfg, *H.host_funcs("hrt"), width=w, height=h, spp=spp)
+        out = {}
+        for label, fl in (("plain", T.FLAG_STREAMED), ("treelets", T.FLAG_STREAMED | T.FLAG_TREELETS)):
+            r.reset_history()
+            a, o = T.alloc_outputs(w, h)
+            r.render_params(p, o, flags=fl)
+            out[label] = a
+        H.assert_outputs_equal(out["plain"], out["treelets"])
+    finally:
+        r.close()
